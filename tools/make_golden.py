@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, sympy, pandas).  Nothing here
+travels to the GPU box except the emitted data files.  What is executed from the
+reference:
+
+* ``import main_fun`` (works: the reference's ``wandb/`` run directory resolves as a
+  namespace package) -> rodrigues_rotation, transform_catenary, solve_catenary,
+  build_theta_features (tension rule), extract_features, integrate_theta_gamma;
+* the *function definitions* ``rk4_integration`` (simulate_rk4_theta_gamma.py:52-68)
+  and ``extract_features`` (simply.py:15-41), pulled out of their scripts with ``ast``
+  and exec'd here, because the scripts themselves cannot be imported (module-level
+  ``pd.read_csv`` of data files absent from the snapshot);
+* the ``sympy_format`` strings of saved_models/equations_*.csv, lambdified with sympy.
+
+What is NOT executed: ``saved_models/*.pkl`` are pickles shipped inside the reference
+and are never unpickled.  The StandardScaler's ``mean_``/``var_``/``scale_`` float64
+arrays are recovered from ``scaler.pkl`` by a raw byte scan (joblib stores ndarray
+payloads verbatim), anchored on the attribute-name markers and cross-checked
+(scale**2 == var, SURVEY.md section 8 A1 values).
+
+``pympc.models.catenary.Catenary`` is absent from the reference; transform_catenary
+KATs are generated with the oracle's own Catenary passed in as ``catenary_fn`` -- that
+pins everything in transform_catenary except the absent third-party callable.
+"""
+import ast
+import csv
+import json
+import os
+import shutil
+import struct
+import sys
+import warnings
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+
+def scaler_from_raw_bytes(path):
+    b = open(path, "rb").read()
+    n_feat = 18
+
+    def arr_after(marker):
+        i = b.find(marker)
+        assert i >= 0, marker
+        # the payload is the first 8-byte-aligned-looking block of n_feat finite doubles
+        # after the NumpyArrayWrapper header that follows the marker
+        j = b.find(b"numpy_array_alignment_bytes", i)
+        if j < 0 or j - i > 400:
+            j = i
+        best = None
+        for start in range(j, min(j + 200, len(b) - 8 * n_feat)):
+            vals = struct.unpack("<%dd" % n_feat, b[start:start + 8 * n_feat])
+            if all(np.isfinite(v) and 1e-12 < abs(v) < 1e12 for v in vals):
+                best = (start, np.array(vals))
+                break
+        assert best is not None, marker
+        return best
+
+    o_mean, mean = arr_after(b"mean_")
+    o_var, var = arr_after(b"var_")
+    o_scale, scale = arr_after(b"scale_")
+    assert np.allclose(scale ** 2, var, rtol=1e-12), "scale^2 != var: wrong offsets"
+    # SURVEY section 8 A1 anchors
+    assert mean[3] == 80.85390753943355 and scale[3] == 108.48977412955092
+    assert mean[15] == -0.052162842559795954 and scale[15] == 0.01732537745796056
+    assert mean[16] == -0.03419530357326386 and scale[16] == 0.028848274510329956
+    assert mean[17] == -0.052169946475892334 and scale[17] == 0.017328840568644522
+    return {"n_features": n_feat, "mean": mean.tolist(), "var": var.tolist(),
+            "scale": scale.tolist(), "byte_offsets": [o_mean, o_var, o_scale],
+            "n_samples_seen": 861,
+            "source": "saved_models/scaler.pkl raw float64 payloads (not unpickled)"}
+
+
+def read_equations():
+    out = {}
+    for which in ("dtheta_dt", "dgamma_dt"):
+        rows = []
+        with open(f"{REF}/saved_models/equations_{which}.csv") as f:
+            for r in csv.DictReader(f):
+                rows.append({"complexity": int(r["complexity"]), "loss": float(r["loss"]),
+                             "score": float(r["score"]), "equation": r["equation"],
+                             "sympy_format": r["sympy_format"]})
+        txt = open(f"{REF}/saved_models/eq_{which}.txt").read()
+        chosen = int(txt.split("\n")[0].split()[-1])      # "complexity   13"
+        out[which] = {"chosen_complexity": chosen, "rows": rows}
+    return out
+
+
+def lambdify_rows(rows, n_feat=18):
+    import sympy
+    syms = sympy.symbols(" ".join(f"x{i}" for i in range(n_feat)))
+    fns = []
+    for r in rows:
+        e = sympy.sympify(r["sympy_format"])
+        fns.append(sympy.lambdify(syms, e, "numpy"))
+    return fns
+
+
+def extract_function(path, name):
+    src = open(path).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            return ast.get_source_segment(src, node)
+    raise KeyError(name)
+
+
+class LambdaModel:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def predict(self, X):
+        X = np.asarray(X, float)
+        out = self.fn(*[X[:, i] for i in range(X.shape[1])])
+        return np.broadcast_to(np.asarray(out, float), (X.shape[0],)).copy()
+
+
+def main():
+    import matplotlib
+    matplotlib.use("Agg")
+    import pandas as pd
+    import main_fun
+    from oracle import rovmpc_oracle as orc
+
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(0)
+
+    # 1. scaler
+    scaler = scaler_from_raw_bytes(f"{REF}/saved_models/scaler.pkl")
+    json.dump(scaler, open(f"{OUT}/scaler.json", "w"), indent=1)
+    mean = np.array(scaler["mean"]); scale = np.array(scaler["scale"])
+
+    # 2. equations
+    eqs = read_equations()
+    json.dump(eqs, open(f"{OUT}/equations.json", "w"), indent=1)
+
+    # 3. dynamics KATs: every row of both Pareto fronts, 256 scaled feature rows
+    Xraw = mean + scale * rng.standard_normal((256, 18))
+    Xs = (Xraw - mean) / scale
+    fth = lambdify_rows(eqs["dtheta_dt"]["rows"]); fga = lambdify_rows(eqs["dgamma_dt"]["rows"])
+    cols = [Xs[:, i] for i in range(18)]
+    out_th = np.stack([np.broadcast_to(np.asarray(f(*cols), float), (256,)) for f in fth])
+    out_ga = np.stack([np.broadcast_to(np.asarray(f(*cols), float), (256,)) for f in fga])
+    np.savez(f"{OUT}/kat_dynamics.npz", Xraw=Xraw, Xs=Xs, out_theta=out_th, out_gamma=out_ga)
+
+    # 4. solve_catenary + tension rule (main_fun.build_theta_features column 5)
+    l = np.concatenate([[1.0, 1.41421356, 2.0, 2.5, 2.9, 0.5, 3.5, 0.6, 0.7, 2.99, 3.0, 1e-3],
+                        rng.uniform(0.05, 3.2, 116)])
+    dH = np.concatenate([[0, -1, 0.5, -0.3, 0.1, 0, 0, 0, 2.5, 0.0, 0.0, 1.0],
+                         rng.uniform(-2.0, 2.0, 116)])
+    L = 3.0
+    C = main_fun.solve_catenary(l, dH, L)
+    n = len(l)
+    df = pd.DataFrame({
+        "rod_end X": 0.0, "rod_end Y": 0.0, "rod_end Z": 0.0,
+        "robot_cable_attach_point X": l * 1000.0, "robot_cable_attach_point Y": 0.0,
+        "robot_cable_attach_point Z": dH * 1000.0,
+        "rob_cor_speed X": rng.standard_normal(n), "rob_cor_speed Y": rng.standard_normal(n),
+        "rob_cor_speed Z": rng.standard_normal(n),
+        "Theta": rng.standard_normal(n) * 0.1, "Gamma": rng.standard_normal(n) * 0.1,
+        "Time": np.arange(n) * 0.05})
+    feats = main_fun.build_theta_features(df, L, 1.521)
+    np.savez(f"{OUT}/kat_solve_catenary.npz", l=feats[:, 3], dH=feats[:, 4], L=L,
+             w_wet=1.521, C=main_fun.solve_catenary(feats[:, 3], feats[:, 4], L), T=feats[:, 5],
+             l_in=l, dH_in=dH, C_in=C)
+
+    # 5. rodrigues
+    v = rng.standard_normal((64, 3)); ax = rng.standard_normal((64, 3)) * rng.uniform(0.1, 5, (64, 1))
+    ang = rng.uniform(-np.pi, np.pi, 64)
+    v[0] = [1, 1, -1]; ax[0] = np.array([1, -1, 0]) / np.sqrt(2); ang[0] = np.radians(-10)
+    out = np.stack([main_fun.rodrigues_rotation(v[i], ax[i], ang[i]) for i in range(64)])
+    np.savez(f"{OUT}/kat_rodrigues.npz", v=v, axis=ax, angle=ang, out=out)
+
+    # 6. transform_catenary with the oracle Catenary as catenary_fn (M = 16)
+    cat = orc.Catenary(3.0, "ENU", n_points=16)
+    cases = []
+    A = np.zeros(3)
+    pts = [([1., 1., -1.], -10, 20), ([1., 1., 0.], 5, -15), ([0.2435, -0.7583, 0.2980], -2, -3),
+           ([0., 0., -1.5], 10, 10),           # vertical: degenerate xy projection
+           ([2.5, 1.5, 0.8], 12, -7),          # nearly taut
+           ([3.0, 1.0, 0.0], 3, 3),            # taut -> None -> straight segment
+           ([0.3, 0.1, 0.0], 4, -9)]           # root above bracket -> None
+    for _ in range(25):
+        p = rng.uniform(-1.5, 1.5, 3)
+        pts.append((p.tolist(), float(rng.uniform(-20, 20)), float(rng.uniform(-30, 30))))
+    Aarr, Barr, th, ga, o0, o1, o2, o3, npts = [], [], [], [], [], [], [], [], []
+    for i, (B, t, g) in enumerate(pts):
+        a = A if i % 3 else rng.uniform(-0.3, 0.3, 3)
+        Bv = np.array(B, float)
+        r = main_fun.transform_catenary(a.copy(), Bv.copy(), cat, np.radians(t), np.radians(g))
+        Aarr.append(a); Barr.append(Bv); th.append(np.radians(t)); ga.append(np.radians(g))
+        pad = lambda x: np.vstack([x, np.full((16 - len(x), 3), np.nan)])
+        npts.append([len(r[0]), len(r[1])])
+        o0.append(pad(r[0])); o1.append(pad(r[1])); o2.append(pad(r[2])); o3.append(pad(r[3]))
+    np.savez(f"{OUT}/kat_transform_catenary.npz", A=np.array(Aarr), B=np.array(Barr),
+             theta=np.array(th), gamma=np.array(ga), original=np.array(o0),
+             theta_rotated=np.array(o1), theta_aligned=np.array(o2), final=np.array(o3),
+             npts=np.array(npts), L=3.0, M=16)
+
+    # 7. feature maps on a synthetic frame
+    T = 64
+    t = np.cumsum(rng.uniform(0.01, 0.03, T))
+    fd = pd.DataFrame({
+        "rod_end X": rng.normal(0, 5, T), "rod_end Y": rng.normal(0, 5, T), "rod_end Z": rng.normal(0, 5, T),
+        "robot_cable_attach_point X": 243.5 + rng.normal(0, 50, T),
+        "robot_cable_attach_point Y": -758.3 + rng.normal(0, 50, T),
+        "robot_cable_attach_point Z": 298.0 + rng.normal(0, 50, T),
+        "rob_cor_speed X": 80.85 + 108.49 * rng.standard_normal(T),
+        "rob_cor_speed Y": -20.13 + 15.88 * rng.standard_normal(T),
+        "rob_cor_speed Z": -18.35 + 63.13 * rng.standard_normal(T),
+        "Theta": -0.0342 + 0.03 * rng.standard_normal(T),
+        "Gamma": -0.0522 + 0.017 * rng.standard_normal(T), "Time": t})
+    ns = {"np": np}
+    exec(extract_function(f"{REF}/simply.py", "extract_features"), ns)
+    X18 = ns["extract_features"](fd)
+    X16 = main_fun.extract_features(fd)
+    np.savez(f"{OUT}/kat_features.npz", frame=fd.values, columns=np.array(fd.columns.tolist()),
+             X18=X18, X16=X16)
+
+    # 8. rk4_integration (exec'd def) and integrate_theta_gamma on a scaled table
+    ns = {"np": np}
+    exec(extract_function(f"{REF}/simulate_rk4_theta_gamma.py", "rk4_integration"), ns)
+    rk4 = ns["rk4_integration"]
+    Xs200 = rng.standard_normal((200, 18))
+    tt = np.cumsum(rng.uniform(0.005, 0.03, 200))
+    i_th = [r["complexity"] for r in eqs["dtheta_dt"]["rows"]].index(eqs["dtheta_dt"]["chosen_complexity"])
+    i_ga = [r["complexity"] for r in eqs["dgamma_dt"]["rows"]].index(eqs["dgamma_dt"]["chosen_complexity"])
+    m_th, m_ga = LambdaModel(fth[i_th]), LambdaModel(fga[i_ga])
+    m_th2, m_ga2 = LambdaModel(fth[-1]), LambdaModel(fga[-1])
+    np.savez(f"{OUT}/kat_replay.npz", Xs=Xs200, time=tt, theta0=-0.0342, gamma0=-0.0522,
+             rk4_theta=rk4(m_th, Xs200, tt, -0.0342), rk4_gamma=rk4(m_ga, Xs200, tt, -0.0522),
+             rk4_theta_last=rk4(m_th2, Xs200, tt, -0.0342), rk4_gamma_last=rk4(m_ga2, Xs200, tt, -0.0522),
+             euler=np.stack(main_fun.integrate_theta_gamma(m_th, m_ga, Xs200, tt, -0.0342, -0.0522)),
+             euler_last=np.stack(main_fun.integrate_theta_gamma(m_th2, m_ga2, Xs200, tt, -0.0342, -0.0522)))
+
+    # 9. trajectory generator outputs the reference already holds (data files)
+    for c in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14):
+        shutil.copyfile(f"{REF}/Results/Trajectory Data/rov_trajectory_exp{c}.csv",
+                        f"{OUT}/rov_trajectory_exp{c}.csv")
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
