@@ -1,0 +1,453 @@
+// rollout_kernels.h -- the fused MPC rollout kernel and its arg-min epilogue (gfx950).
+//
+// One workgroup owns CK consecutive candidates and ALL N horizon steps of them.  The
+// candidate-control chunk U[k0:k0+CK][N][3] is contiguous in HBM and is read exactly once,
+// coalesced, into LDS; everything else lives in LDS/registers until the K costs, the
+// per-block best and (optionally) the trajectories are written.
+//
+//   phase 0  U chunk -> LDS (coalesced)                                  all threads
+//   phase 1  P1 prefix  P_{n+1} = P_n + (v_scale dt) U_n                 3*CK threads, N steps
+//   phase 2  exogenous feature rows (simply.py:25-31) of every node,     (N+1)*CK items
+//            scaled (scaler.pkl), + rotation axes (main_fun.py:75-103)
+//   phase 3  closed-loop RK4 / Euler over the horizon                    CK threads, N steps
+//            (simulate_rk4_theta_gamma.py:52-68 with the state fed back; velocity
+//             transform v_cat = R_theta(theta) R_gamma(-gamma) v when VT == COMPOSE)
+//   phase 4  per node: catenary parameter + tension (main_fun.py:418-431, 302-305),
+//            augmented-catenary lowest point (main_fun.py:38-111), cost  N*CK items
+//   phase 5  J_k = sum_n cost, NaN -> +inf, wave arg-min, outputs        CK threads
+//
+// Only phase 3 is sequential in n; phases 2 and 4 expose K*N-way parallelism, which is what
+// fills the chip at K = 4096 (64 waves' worth of candidates).
+#pragma once
+#include "device_math.h"
+
+namespace rovmpc {
+
+constexpr int MODEL_BUILTIN = 0;   // saved_models/eq_*.txt rows (complexity 13 / 3), compiled in
+constexpr int MODEL_INTERP  = 1;   // any bytecode
+
+constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
+constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + unit_rel (x,y,z)
+
+template <typename T> struct RolloutArgs {
+    const T *U;               // [K][N][3]
+    const double *state;      // 16 doubles (rovmpc_state)
+    const int32_t *code_th, *code_ga;
+    const T *consts;
+    const T *Rtab;            // [N][9] (VT_TABLE)
+    T *J;                     // [K]
+    T *traj_all;              // [K][N+1][2] or null
+    double *blk_cost;         // [nblocks]
+    long long *blk_idx;       // [nblocks]
+    double *blk_traj;         // [nblocks][N+1][2]
+    int N, K, CK, M, n_th, n_ga, prev_mode, integrator;
+    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up;
+    T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
+    T Uref[3];
+    T mean[18], inv_scale[18];
+};
+
+// ---- learned dynamics ---------------------------------------------------------------------
+
+// Bytecode interpreter.  All lanes run the same program (uniform control flow, scalar
+// instruction fetch); the operand stack lives in LDS ([depth][lane], conflict-free) with the
+// top of stack cached in a register.
+template <typename T>
+RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restrict__ consts,
+                     const T *feat, int fstride, T *stack, int sstride) {
+    T top = T(0);
+    int sp = 0;
+    for (int pc = 0; pc < n; ++pc) {
+        int ins = code[pc];
+        int op = ins & 0xff, arg = ins >> 8;
+        switch (op) {
+        case ROVMPC_OP_PUSH_C:
+            if (sp > 0) stack[(sp - 1) * sstride] = top;
+            top = consts[arg]; ++sp; break;
+        case ROVMPC_OP_PUSH_F:
+            if (sp > 0) stack[(sp - 1) * sstride] = top;
+            top = feat[arg * fstride]; ++sp; break;
+        case ROVMPC_OP_ADD: top = stack[(sp - 2) * sstride] + top; --sp; break;
+        case ROVMPC_OP_SUB: top = stack[(sp - 2) * sstride] - top; --sp; break;
+        case ROVMPC_OP_MUL: top = stack[(sp - 2) * sstride] * top; --sp; break;
+        case ROVMPC_OP_DIV: top = stack[(sp - 2) * sstride] / top; --sp; break;
+        case ROVMPC_OP_POW: top = m_pow(stack[(sp - 2) * sstride], top); --sp; break;
+        case ROVMPC_OP_NEG: top = -top; break;
+        case ROVMPC_OP_SIN: top = m_sin(top); break;
+        case ROVMPC_OP_COS: top = m_cos(top); break;
+        case ROVMPC_OP_TANH: top = m_tanh(top); break;
+        case ROVMPC_OP_ABS: top = m_abs(top); break;
+        case ROVMPC_OP_SQUARE: top = top * top; break;
+        case ROVMPC_OP_EXP: top = m_exp(top); break;
+        case ROVMPC_OP_LOG: top = m_log(top); break;
+        case ROVMPC_OP_SQRT: top = m_sqrt(top); break;
+        case ROVMPC_OP_POWI: {
+            int e = arg >= (1 << 23) ? arg - (1 << 24) : arg;     // signed 24-bit
+            int ae = e < 0 ? -e : e;
+            T b = top, r = T(1);
+            while (ae) { if (ae & 1) r *= b; b *= b; ae >>= 1; }
+            top = e < 0 ? T(1) / r : r; break;
+        }
+        case ROVMPC_OP_SAFE_LOG: top = m_log(m_abs(top) + T(1e-5)); break;
+        case ROVMPC_OP_SAFE_SQRT: top = m_sqrt(m_abs(top)); break;
+        default: top = m_nan<T>(); break;
+        }
+    }
+    return top;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------
+
+// LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
+#define RV_PL(base, p, n, c) (base)[((p) * (N + 1) + (n)) * CK + (c)]
+
+template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt) {
+    size_t planes = 3 /*P*/ + NEXO + 2 /*theta,gamma*/ + (vt == ROVMPC_VT_COMPOSE ? NAX : 0);
+    size_t e = 4;                                    // header (block-best lane)
+    e += planes * (size_t)(N + 1) * CK;              // node planes
+    e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
+    e += (size_t)CK * N;                             // node costs
+    if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
+    return e;
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(256)
+rollout_kernel(const RolloutArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *smem = reinterpret_cast<T *>(smem_raw);
+    const int N = a.N, CK = a.CK, K = a.K;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int k0 = blockIdx.x * CK;
+    const int nvalid = min(CK, K - k0);
+
+    // carve LDS
+    int *s_best_c = reinterpret_cast<int *>(smem);   // header
+    const int US = (3 * N) | 1;                      // padded U row stride
+    T *sP = smem + 4;                                // 3 planes
+    T *sX = sP + 3 * (N + 1) * CK;                   // NEXO planes (scaled features)
+    T *sY = sX + NEXO * (N + 1) * CK;                // theta, gamma planes
+    T *sA = sY + 2 * (N + 1) * CK;                   // NAX planes (COMPOSE only)
+    T *sU = sA + (VT == ROVMPC_VT_COMPOSE ? NAX * (N + 1) * CK : 0);   // [c][n][3]
+    T *sC = sU + CK * US;                            // [n][c] node costs
+    T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
+
+    // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
+    {
+        const T *src = a.U + (size_t)k0 * N * 3;
+        const int tot = nvalid * N * 3;
+        for (int i = tid; i < CK * N * 3; i += NT) {
+            const int c = i / (3 * N), j = i - c * (3 * N);
+            sU[c * US + j] = (i < tot) ? src[i] : T(0);
+        }
+    }
+    // state (uniform loads)
+    const double *sd = a.state;
+    const T P0x = (T)sd[0], P0y = (T)sd[1], P0z = (T)sd[2];
+    const T V0x = (T)sd[6], V0y = (T)sd[7], V0z = (T)sd[8];
+    const T A0x = (T)sd[9], A0y = (T)sd[10], A0z = (T)sd[11];
+    const T th0 = (T)sd[12], ga0 = (T)sd[13], thm0 = (T)sd[14], gam0 = (T)sd[15];
+    __syncthreads();
+
+    // ---- phase 1: position prefix along the horizon ---------------------------------------
+    if (tid < 3 * CK) {
+        const int ax = tid / CK, c = tid % CK;
+        T p = (T)sd[3 + ax];
+        RV_PL(sP, ax, 0, c) = p;
+        for (int n = 0; n < N; ++n) {
+            p = p + a.vs_h * sU[c * US + n * 3 + ax];
+            RV_PL(sP, ax, n + 1, c) = p;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: exogenous feature rows of every node ------------------------------------
+    for (int i = tid; i < (N + 1) * CK; i += NT) {
+        const int n = i / CK, c = i % CK;
+        const T Px = RV_PL(sP, 0, n, c), Py = RV_PL(sP, 1, n, c), Pz = RV_PL(sP, 2, n, c);
+        const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
+        const T nr = m_sqrt(rx * rx + ry * ry + rz * rz);
+        const T inr = T(1) / (nr + T(1e-8));                                 // :26
+        const T ux = rx * inr, uy = ry * inr, uz = rz * inr;
+        const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
+        RV_PL(sX, 0, n, c) = (Px - a.mean[0]) * a.inv_scale[0];
+        RV_PL(sX, 1, n, c) = (Py - a.mean[1]) * a.inv_scale[1];
+        RV_PL(sX, 2, n, c) = (Pz - a.mean[2]) * a.inv_scale[2];
+        RV_PL(sX, 9, n, c) = (ux - a.mean[9]) * a.inv_scale[9];
+        RV_PL(sX, 10, n, c) = (uy - a.mean[10]) * a.inv_scale[10];
+        RV_PL(sX, 11, n, c) = (uz - a.mean[11]) * a.inv_scale[11];
+        RV_PL(sX, 12, n, c) = (tension - a.mean[12]) * a.inv_scale[12];
+        if (VT == ROVMPC_VT_COMPOSE) {
+            V3<T> kt, kg;
+            theta_gamma_axes<T>({rx, ry, rz}, kt, kg);
+            RV_PL(sA, 0, n, c) = kt.x; RV_PL(sA, 1, n, c) = kt.y;
+            RV_PL(sA, 2, n, c) = kg.x; RV_PL(sA, 3, n, c) = kg.y; RV_PL(sA, 4, n, c) = kg.z;
+            RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
+        } else {
+            // velocity features do not depend on (theta, gamma): finish the row here
+            T Vx, Vy, Vz, Wx, Wy, Wz;           // V_n and V_{n-1}
+            auto vel = [&](int node, T &vx, T &vy, T &vz) {
+                if (node == 0) { vx = V0x; vy = V0y; vz = V0z; return; }
+                const T *u = &sU[c * US + (node - 1) * 3];
+                if (VT == ROVMPC_VT_TABLE) {
+                    const T *R = a.Rtab + (node - 1) * 9;                    // R @ v
+                    vx = R[0] * u[0] + R[1] * u[1] + R[2] * u[2];
+                    vy = R[3] * u[0] + R[4] * u[1] + R[5] * u[2];
+                    vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
+                } else { vx = u[0]; vy = u[1]; vz = u[2]; }
+            };
+            vel(n, Vx, Vy, Vz);
+            T Ax, Ay, Az;
+            if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
+            else { vel(n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * a.inv_h; Ay = (Vy - Wy) * a.inv_h; Az = (Vz - Wz) * a.inv_h; }
+            const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
+            const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));   // :31
+            RV_PL(sX, 3, n, c) = (Vx - a.mean[3]) * a.inv_scale[3];
+            RV_PL(sX, 4, n, c) = (Vy - a.mean[4]) * a.inv_scale[4];
+            RV_PL(sX, 5, n, c) = (Vz - a.mean[5]) * a.inv_scale[5];
+            RV_PL(sX, 6, n, c) = (Ax - a.mean[6]) * a.inv_scale[6];
+            RV_PL(sX, 7, n, c) = (Ay - a.mean[7]) * a.inv_scale[7];
+            RV_PL(sX, 8, n, c) = (Az - a.mean[8]) * a.inv_scale[8];
+            RV_PL(sX, 13, n, c) = (ap - a.mean[13]) * a.inv_scale[13];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: closed-loop integration of (theta, gamma) -------------------------------
+    if (tid < CK) {
+        const int c = tid;
+        T th = th0, ga = ga0, thm = thm0, gam = gam0;
+        RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
+        // COMPOSE: velocity-dependent scaled slots of node n (3..8, 13) carried in registers
+        T Vx = V0x, Vy = V0y, Vz = V0z;
+        if (VT == ROVMPC_VT_COMPOSE) {
+            const T ux = RV_PL(sA, 5, 0, c), uy = RV_PL(sA, 6, 0, c), uz = RV_PL(sA, 7, 0, c);
+            const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);
+            const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));
+            RV_PL(sX, 3, 0, c) = (Vx - a.mean[3]) * a.inv_scale[3];
+            RV_PL(sX, 4, 0, c) = (Vy - a.mean[4]) * a.inv_scale[4];
+            RV_PL(sX, 5, 0, c) = (Vz - a.mean[5]) * a.inv_scale[5];
+            RV_PL(sX, 6, 0, c) = (A0x - a.mean[6]) * a.inv_scale[6];
+            RV_PL(sX, 7, 0, c) = (A0y - a.mean[7]) * a.inv_scale[7];
+            RV_PL(sX, 8, 0, c) = (A0z - a.mean[8]) * a.inv_scale[8];
+            RV_PL(sX, 13, 0, c) = (ap - a.mean[13]) * a.inv_scale[13];
+        }
+        for (int n = 0; n < N; ++n) {
+            if (VT == ROVMPC_VT_COMPOSE) {
+                // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world,
+                // axes of the cable at node n (R @ v of velocity_transform_batch.py:100-101
+                // with R composed from the augmentation angles)
+                const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
+                const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+                T st, ct, sg, cg;
+                m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg);
+                const T *u = &sU[c * US + n * 3];
+                V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
+                v = rodrigues_unit<T>(v, kt, st, ct);
+                const T Ax = (v.x - Vx) * a.inv_h, Ay = (v.y - Vy) * a.inv_h, Az = (v.z - Vz) * a.inv_h;
+                Vx = v.x; Vy = v.y; Vz = v.z;
+                const T ux = RV_PL(sA, 5, n + 1, c), uy = RV_PL(sA, 6, n + 1, c), uz = RV_PL(sA, 7, n + 1, c);
+                const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);
+                const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));
+                RV_PL(sX, 3, n + 1, c) = (Vx - a.mean[3]) * a.inv_scale[3];
+                RV_PL(sX, 4, n + 1, c) = (Vy - a.mean[4]) * a.inv_scale[4];
+                RV_PL(sX, 5, n + 1, c) = (Vz - a.mean[5]) * a.inv_scale[5];
+                RV_PL(sX, 6, n + 1, c) = (Ax - a.mean[6]) * a.inv_scale[6];
+                RV_PL(sX, 7, n + 1, c) = (Ay - a.mean[7]) * a.inv_scale[7];
+                RV_PL(sX, 8, n + 1, c) = (Az - a.mean[8]) * a.inv_scale[8];
+                RV_PL(sX, 13, n + 1, c) = (ap - a.mean[13]) * a.inv_scale[13];
+            }
+            // delay slots x16, x17 at the two ends of the step (np.roll semantics, simply.py:35-38)
+            const T s16a = (thm - a.mean[16]) * a.inv_scale[16], s16b = (th - a.mean[16]) * a.inv_scale[16];
+            const T s17a = (gam - a.mean[17]) * a.inv_scale[17], s17b = (ga - a.mean[17]) * a.inv_scale[17];
+            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+
+            // one stage: f(features(y, t_n + cfrac h)); cfrac in {0, 1/2, 1}
+            auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
+                T p16, p17;
+                if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
+                else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
+                else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
+                const T x14 = (yth - a.mean[14]) * a.inv_scale[14];
+                const T x15 = (yga - a.mean[15]) * a.inv_scale[15];
+                auto exo = [&](int slot) -> T {
+                    if (cfrac2 == 0) return RV_PL(sX, slot, n, c);
+                    if (cfrac2 == 2) return RV_PL(sX, slot, n + 1, c);
+                    return (RV_PL(sX, slot, n, c) + RV_PL(sX, slot, n + 1, c)) / T(2);   // :62
+                };
+                if (MODEL == MODEL_BUILTIN) {
+                    // saved_models/equations_dtheta_dt.csv complexity 13:
+                    //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)
+                    // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
+                    const T x3 = exo(3);
+                    dth = (((m_sin(p17) - m_sin(x3)) - p16) - x3) * T(0.048152514);
+                    dga = x15 - p17;
+                } else {
+                    T *feat = sF + c;                       // [slot][lane]
+                    T *stack = sF + 18 * CK + c;
+                    for (int s = 0; s < NEXO; ++s) feat[s * CK] = exo(s);
+                    feat[14 * CK] = x14; feat[15 * CK] = x15; feat[16 * CK] = p16; feat[17 * CK] = p17;
+                    dth = interp_eval<T>(a.code_th, a.n_th, a.consts, feat, CK, stack, CK);
+                    dga = interp_eval<T>(a.code_ga, a.n_ga, a.consts, feat, CK, stack, CK);
+                }
+            };
+
+            T k1t, k1g;
+            stage(th, ga, 0, k1t, k1g);
+            T thn, gan;
+            if (a.integrator == ROVMPC_EULER) {
+                thn = th + k1t * a.h;                                         // main_fun.py:761
+                gan = ga + k1g * a.h;
+            } else {
+                T k2t, k2g, k3t, k3g, k4t, k4g;
+                const T hh = T(0.5) * a.h;
+                stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
+                stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
+                stage(th + a.h * k3t, ga + a.h * k3g, 2, k4t, k4g);
+                const T h6 = a.h / T(6);
+                thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);        // :66
+                gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
+            }
+            thm = th; gam = ga; th = thn; ga = gan;
+            RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: per-node geometry and cost ----------------------------------------------
+    for (int i = tid; i < N * CK; i += NT) {
+        const int n = i / CK, c = i % CK;
+        const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
+                rz = RV_PL(sP, 2, n + 1, c) - P0z;
+        const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
+        const T *u = &sU[c * US + n * 3];
+        const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
+        const T dH = a.up * rz;                                              // :293
+        const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
+        const T C = solve_catenary_C<T>(l, dH, a.L, a.c_lo, a.c_hi);         // :303
+        const T Tn = cable_tension<T>(l, C, a.w_per_len);                    // :304-305
+        const T zl = P0z + augmented_lowest_z<T>({rx, ry, rz}, th, ga, a.L, a.M, a.up, a.c_lo, a.c_hi);
+        const T eth = th - a.theta_ref, ega = ga - a.gamma_ref;
+        const T e0 = u[0] - a.Uref[0], e1 = u[1] - a.Uref[1], e2 = u[2] - a.Uref[2];
+        const T taut = m_max(T(0), d - a.rhoL);
+        const T flo = m_max(T(0), a.up * (a.z_floor - zl));
+        T cost = a.w_theta * (eth * eth) + a.w_gamma * (ega * ega) + a.w_u * (e0 * e0 + e1 * e1 + e2 * e2)
+               + a.w_T * Tn + a.w_taut * (taut * taut) + a.w_floor * (flo * flo);
+        sC[n * CK + c] = cost;
+    }
+    __syncthreads();
+
+    // ---- phase 5: J_k, block arg-min, outputs ---------------------------------------------
+    if (tid < 64) {
+        const int c = tid;
+        double Jd = __builtin_inf();
+        long long kk = 0x7fffffffffffffffLL;
+        if (c < nvalid) {
+            T J = T(0);
+            for (int n = 0; n < N; ++n) J = J + sC[n * CK + c];
+            if (J != J) J = m_inf<T>();                  // NaN cost never wins the arg-min
+            a.J[k0 + c] = J;
+            Jd = (double)J; kk = k0 + c;
+        }
+        // wave arg-min, lowest index on ties (np.argmin)
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oJ = __shfl_down(Jd, off, 64);
+            const long long ok = __shfl_down(kk, off, 64);
+            if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+        }
+        if (c == 0) {
+            a.blk_cost[blockIdx.x] = Jd;
+            a.blk_idx[blockIdx.x] = kk;
+            *s_best_c = (int)(kk - k0);
+        }
+    }
+    __syncthreads();
+    {
+        const int cb = *s_best_c;
+        double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
+        for (int i = tid; i < (N + 1); i += NT) {
+            bt[2 * i] = (double)RV_PL(sY, 0, i, cb);
+            bt[2 * i + 1] = (double)RV_PL(sY, 1, i, cb);
+        }
+        if (a.traj_all) {
+            for (int i = tid; i < nvalid * (N + 1); i += NT) {
+                const int c = i / (N + 1), n = i % (N + 1);
+                T *dst = a.traj_all + ((size_t)(k0 + c) * (N + 1) + n) * 2;
+                dst[0] = RV_PL(sY, 0, n, c); dst[1] = RV_PL(sY, 1, n, c);
+            }
+        }
+    }
+}
+
+// ---- arg-min epilogue ----------------------------------------------------------------------
+// One workgroup: lexicographic (cost, index) minimum over the per-block bests, then the
+// result record [J*, k*, u(3), (theta,gamma)_0..N].  If slots != null also writes the
+// order-preserving int64 image of the record into slots[rank][*] and INT64_MAX elsewhere
+// (input of the single all-reduce(min) of the candidate-sharded step).
+template <typename T>
+__global__ void __launch_bounds__(256)
+finalize_kernel(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
+                const T *U, int N, int CK, double *result, long long k_offset,
+                long long *slots, int rank, int world) {
+    __shared__ double sJ[4];
+    __shared__ long long sK[4];
+    __shared__ long long s_k;
+    const int tid = threadIdx.x;
+    double Jd = __builtin_inf();
+    long long kk = 0x7fffffffffffffffLL;
+    for (int b = tid; b < nblocks; b += blockDim.x) {
+        const double oJ = blk_cost[b]; const long long ok = blk_idx[b];
+        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oJ = __shfl_down(Jd, off, 64);
+        const long long ok = __shfl_down(kk, off, 64);
+        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+    }
+    if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (sJ[w] < Jd || (sJ[w] == Jd && sK[w] < kk)) { Jd = sJ[w]; kk = sK[w]; }
+        s_k = kk;
+        sJ[0] = Jd;
+    }
+    __syncthreads();
+    const long long kbest = s_k;
+    const int R = 5 + 2 * (N + 1);
+    const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
+    for (int i = tid; i < R; i += blockDim.x) {
+        double v;
+        if (i == 0) v = sJ[0];
+        else if (i == 1) v = (double)(kbest + k_offset);
+        else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
+        else v = bt[i - 5];
+        result[i] = v;
+        if (slots) slots[(size_t)rank * R + i] = ordered_key(v);
+    }
+    if (slots) {
+        for (int i = tid; i < world * R; i += blockDim.x)
+            if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
+    }
+}
+
+// After the all-reduce(min): every rank holds every rank's record; pick the lexicographic
+// (cost, global index) minimum and decode it.
+__global__ void __launch_bounds__(64)
+select_kernel(const long long *slots, int world, int R, double *result) {
+    __shared__ int s_r;
+    if (threadIdx.x == 0) {
+        double Jd = __builtin_inf(); double kd = __builtin_inf(); int rb = 0;
+        for (int r = 0; r < world; ++r) {
+            const double oJ = ordered_val(slots[(size_t)r * R]);
+            const double ok = ordered_val(slots[(size_t)r * R + 1]);
+            if (oJ < Jd || (oJ == Jd && ok < kd) || r == 0) { Jd = oJ; kd = ok; rb = r; }
+        }
+        s_r = rb;
+    }
+    __syncthreads();
+    const int rb = s_r;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = ordered_val(slots[(size_t)rb * R + i]);
+}
+
+}  // namespace rovmpc

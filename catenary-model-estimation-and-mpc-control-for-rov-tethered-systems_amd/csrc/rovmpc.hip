@@ -1,0 +1,655 @@
+// rovmpc.hip -- C ABI (include/rovmpc.h) over the HIP kernels.  gfx950 only, no torch types.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "util_kernels.h"
+
+using namespace rovmpc;
+
+static thread_local std::string g_create_error;
+
+struct rovmpc_handle {
+    rovmpc_config cfg;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // model
+    bool has_model = false, builtin = false;
+    int n_feat = 0;
+    double mean[ROVMPC_MAX_FEATURES], scale[ROVMPC_MAX_FEATURES];
+    int n_th = 0, n_ga = 0, n_consts = 0;
+    int32_t *d_code_th = nullptr, *d_code_ga = nullptr;
+    void *d_consts = nullptr;        // T
+    double *d_consts64 = nullptr;    // double (utility kernels)
+    void *d_Rtab = nullptr;          // T [N][9]
+    bool has_rtab = false;
+    // launch geometry / workspace
+    int CK = 0, nblocks = 0, NT = 0;
+    size_t lds_bytes = 0, esz = 8;
+    void *d_U = nullptr, *d_J = nullptr, *d_traj_all = nullptr;
+    double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
+    long long *d_blk_idx = nullptr;
+    double *h_result = nullptr;      // pinned
+    // timing
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    bool timing = false;
+};
+
+#define FAIL(h, code, ...)                                        \
+    do {                                                          \
+        char _b[512];                                             \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                    \
+        if (h) (h)->err = _b; else g_create_error = _b;           \
+        return (code);                                            \
+    } while (0)
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            FAIL(h, ROVMPC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),  \
+                 __FILE__, __LINE__);                                                       \
+    } while (0)
+
+extern "C" const char *rovmpc_version(void) { return "rovmpc 0.1 (gfx950)"; }
+
+extern "C" void rovmpc_default_config(rovmpc_config *c) {
+    memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(rovmpc_config);
+    c->device = 0; c->dtype = ROVMPC_F64; c->N = 20; c->K = 4096; c->n_shape_pts = 16;
+    c->vt_mode = ROVMPC_VT_COMPOSE; c->prev_mode = ROVMPC_PREV_INTERP; c->integrator = ROVMPC_RK4;
+    c->frame = ROVMPC_ENU; c->force_interpreter = 0; c->candidates_per_block = 0;
+    c->dt = 1.0 / 60.0; c->v_scale = 1e-3; c->L = 3.0; c->cable_wet_weight = 1.521;
+    c->c_lo = 1e-6; c->c_hi = 10.0;
+    c->w_theta = 1.0; c->w_gamma = 1.0; c->w_u = 1e-6; c->w_T = 1e-2; c->w_taut = 1e3;
+    c->rho_taut = 0.98; c->w_floor = 10.0; c->z_floor = -1.2;
+}
+
+extern "C" const char *rovmpc_last_error(const rovmpc_handle *h) {
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int32_t rovmpc_result_len(const rovmpc_handle *h) { return h ? 5 + 2 * (h->cfg.N + 1) : 0; }
+
+static int pick_ck(int K, int req) {
+    if (req > 0) return req;
+    int ck = 1;
+    while (ck < 16 && K / (ck * 2) >= 1024) ck *= 2;     // aim at ~4 resident workgroups per CU
+    return ck;
+}
+
+template <typename T> static size_t lds_bytes_for(const rovmpc_handle *h, int model, int vt) {
+    return rollout_lds_elems<T>(h->cfg.N, h->CK, model, vt) * sizeof(T);
+}
+
+extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
+    rovmpc_handle *nullh = nullptr;
+    if (!cfg || !out) FAIL(nullh, ROVMPC_ERR_INVALID, "rovmpc_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(rovmpc_config))
+        FAIL(nullh, ROVMPC_ERR_INVALID, "rovmpc_create: struct_size %d != %d (ABI mismatch)", cfg->struct_size,
+             (int)sizeof(rovmpc_config));
+    if (cfg->N < 1 || cfg->N > 4096) FAIL(nullh, ROVMPC_ERR_INVALID, "N must be in 1..4096 (got %d)", cfg->N);
+    if (cfg->K < 1) FAIL(nullh, ROVMPC_ERR_INVALID, "K must be >= 1 (got %d)", cfg->K);
+    if (cfg->dtype != ROVMPC_F64 && cfg->dtype != ROVMPC_F32) FAIL(nullh, ROVMPC_ERR_INVALID, "bad dtype %d", cfg->dtype);
+    if (cfg->n_shape_pts < 2) FAIL(nullh, ROVMPC_ERR_INVALID, "n_shape_pts must be >= 2");
+    if (cfg->vt_mode < 0 || cfg->vt_mode > 2) FAIL(nullh, ROVMPC_ERR_INVALID, "bad vt_mode %d", cfg->vt_mode);
+    if (cfg->prev_mode < 0 || cfg->prev_mode > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad prev_mode %d", cfg->prev_mode);
+    if (cfg->integrator < 0 || cfg->integrator > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad integrator %d", cfg->integrator);
+    if (cfg->frame < 0 || cfg->frame > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad frame %d", cfg->frame);
+    if (!(cfg->dt > 0) || !(cfg->L > 0) || !(cfg->c_lo > 0) || !(cfg->c_hi > cfg->c_lo))
+        FAIL(nullh, ROVMPC_ERR_INVALID, "dt, L must be > 0 and 0 < c_lo < c_hi");
+    if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64)
+        FAIL(nullh, ROVMPC_ERR_INVALID, "candidates_per_block must be 0..64");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        FAIL(nullh, ROVMPC_ERR_HIP, "no HIP device available (%s); librovmpc has no CPU fallback",
+             e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (cfg->device < 0 || cfg->device >= ndev) FAIL(nullh, ROVMPC_ERR_INVALID, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+
+    rovmpc_handle *h = new rovmpc_handle();
+    h->cfg = *cfg;
+    h->esz = cfg->dtype == ROVMPC_F64 ? 8 : 4;
+    h->CK = pick_ck(cfg->K, cfg->candidates_per_block);
+    h->nblocks = (cfg->K + h->CK - 1) / h->CK;
+    int items = (cfg->N + 1) * h->CK;
+    h->NT = items >= 256 ? 256 : ((items + 63) / 64) * 64;
+    if (h->NT < 64) h->NT = 64;
+    // worst-case LDS over the model/vt variants this handle may launch
+    size_t need = cfg->dtype == ROVMPC_F64 ? lds_bytes_for<double>(h, MODEL_INTERP, cfg->vt_mode)
+                                           : lds_bytes_for<float>(h, MODEL_INTERP, cfg->vt_mode);
+    if (need > 160 * 1024) {
+        g_create_error = "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
+        delete h;
+        return ROVMPC_ERR_INVALID;
+    }
+#define CR(call)                                                                         \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            char _b[256];                                                                \
+            snprintf(_b, sizeof(_b), "%s failed: %s", #call, hipGetErrorString(_e));     \
+            g_create_error = _b;                                                         \
+            rovmpc_destroy(h);                                                           \
+            return ROVMPC_ERR_HIP;                                                       \
+        }                                                                                \
+    } while (0)
+    CR(hipSetDevice(cfg->device));
+    CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t R = 5 + 2 * (size_t)(cfg->N + 1);
+    CR(hipMalloc(&h->d_U, (size_t)cfg->K * cfg->N * 3 * h->esz));
+    CR(hipMalloc(&h->d_J, (size_t)cfg->K * h->esz));
+    CR(hipMalloc((void **)&h->d_state, ROVMPC_STATE_LEN * sizeof(double)));
+    CR(hipMalloc((void **)&h->d_blk_cost, h->nblocks * sizeof(double)));
+    CR(hipMalloc((void **)&h->d_blk_idx, h->nblocks * sizeof(long long)));
+    CR(hipMalloc((void **)&h->d_blk_traj, (size_t)h->nblocks * (cfg->N + 1) * 2 * sizeof(double)));
+    CR(hipMalloc((void **)&h->d_result, R * sizeof(double)));
+    CR(hipHostMalloc((void **)&h->h_result, R * sizeof(double), hipHostMallocDefault));
+    CR(hipMalloc((void **)&h->d_code_th, ROVMPC_MAX_CODE * sizeof(int32_t)));
+    CR(hipMalloc((void **)&h->d_code_ga, ROVMPC_MAX_CODE * sizeof(int32_t)));
+    CR(hipMalloc(&h->d_consts, ROVMPC_MAX_CODE * 8));
+    CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
+    CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
+#undef CR
+    *out = h;
+    return ROVMPC_OK;
+}
+
+extern "C" void rovmpc_destroy(rovmpc_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_result) (void)hipHostFree(h->h_result);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// ---- model ---------------------------------------------------------------------------------
+
+// Host-side evaluation of a bytecode program; used ONLY to fingerprint a loaded model against
+// the compiled-in default equations (never to produce results).
+static double host_eval(const int32_t *code, int n, const double *consts, const double *x) {
+    double st[ROVMPC_MAX_STACK + 1];
+    int sp = 0;
+    for (int pc = 0; pc < n; ++pc) {
+        int op = code[pc] & 0xff, arg = code[pc] >> 8;
+        switch (op) {
+        case ROVMPC_OP_PUSH_C: st[sp++] = consts[arg]; break;
+        case ROVMPC_OP_PUSH_F: st[sp++] = x[arg]; break;
+        case ROVMPC_OP_ADD: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
+        case ROVMPC_OP_SUB: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
+        case ROVMPC_OP_MUL: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
+        case ROVMPC_OP_DIV: st[sp - 2] = st[sp - 2] / st[sp - 1]; --sp; break;
+        case ROVMPC_OP_POW: st[sp - 2] = pow(st[sp - 2], st[sp - 1]); --sp; break;
+        case ROVMPC_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
+        case ROVMPC_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
+        case ROVMPC_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
+        case ROVMPC_OP_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
+        case ROVMPC_OP_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
+        case ROVMPC_OP_SQUARE: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;
+        case ROVMPC_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
+        case ROVMPC_OP_LOG: st[sp - 1] = log(st[sp - 1]); break;
+        case ROVMPC_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
+        case ROVMPC_OP_POWI: {
+            int e = arg >= (1 << 23) ? arg - (1 << 24) : arg;
+            st[sp - 1] = pow(st[sp - 1], (double)e); break;
+        }
+        case ROVMPC_OP_SAFE_LOG: st[sp - 1] = log(fabs(st[sp - 1]) + 1e-5); break;
+        case ROVMPC_OP_SAFE_SQRT: st[sp - 1] = sqrt(fabs(st[sp - 1])); break;
+        default: return NAN;
+        }
+    }
+    return sp == 1 ? st[0] : NAN;
+}
+
+// Static validation: opcodes known, indices in range, stack discipline, final depth 1.
+static const char *validate_code(const int32_t *code, int n, int n_feat, int n_consts) {
+    if (n < 1 || n > ROVMPC_MAX_CODE) return "program length out of range";
+    int sp = 0;
+    for (int pc = 0; pc < n; ++pc) {
+        int op = code[pc] & 0xff, arg = code[pc] >> 8;
+        switch (op) {
+        case ROVMPC_OP_PUSH_C: if (arg < 0 || arg >= n_consts) return "constant index out of range"; ++sp; break;
+        case ROVMPC_OP_PUSH_F: if (arg < 0 || arg >= n_feat) return "feature index out of range"; ++sp; break;
+        case ROVMPC_OP_ADD: case ROVMPC_OP_SUB: case ROVMPC_OP_MUL: case ROVMPC_OP_DIV: case ROVMPC_OP_POW:
+            if (sp < 2) return "stack underflow"; --sp; break;
+        case ROVMPC_OP_NEG: case ROVMPC_OP_SIN: case ROVMPC_OP_COS: case ROVMPC_OP_TANH: case ROVMPC_OP_ABS:
+        case ROVMPC_OP_SQUARE: case ROVMPC_OP_EXP: case ROVMPC_OP_LOG: case ROVMPC_OP_SQRT: case ROVMPC_OP_POWI:
+        case ROVMPC_OP_SAFE_LOG: case ROVMPC_OP_SAFE_SQRT:
+            if (sp < 1) return "stack underflow"; break;
+        default: return "unknown opcode";
+        }
+        if (sp > ROVMPC_MAX_STACK) return "expression needs more than ROVMPC_MAX_STACK operands";
+    }
+    return sp == 1 ? nullptr : "program does not leave exactly one value";
+}
+
+extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const double *mean, const double *scale,
+                                const int32_t *code_theta, int32_t n_code_theta, const int32_t *code_gamma,
+                                int32_t n_code_gamma, const double *consts, int32_t n_consts) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!mean || !scale || !code_theta || !code_gamma || (n_consts > 0 && !consts))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_set_model: null argument");
+    if (n_features < 1 || n_features > ROVMPC_MAX_FEATURES) FAIL(h, ROVMPC_ERR_INVALID, "n_features out of range");
+    if (n_consts < 0 || n_consts > ROVMPC_MAX_CODE) FAIL(h, ROVMPC_ERR_INVALID, "n_consts out of range");
+    const char *why;
+    if ((why = validate_code(code_theta, n_code_theta, n_features, n_consts))) FAIL(h, ROVMPC_ERR_INVALID, "theta program: %s", why);
+    if ((why = validate_code(code_gamma, n_code_gamma, n_features, n_consts))) FAIL(h, ROVMPC_ERR_INVALID, "gamma program: %s", why);
+    for (int i = 0; i < n_features; ++i)
+        if (!(scale[i] != 0.0) || !isfinite(scale[i]) || !isfinite(mean[i])) FAIL(h, ROVMPC_ERR_INVALID, "scaler entry %d is not finite / zero scale", i);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->n_feat = n_features;
+    memcpy(h->mean, mean, n_features * sizeof(double));
+    memcpy(h->scale, scale, n_features * sizeof(double));
+    h->n_th = n_code_theta; h->n_ga = n_code_gamma; h->n_consts = n_consts;
+    HIPCHK(h, hipMemcpy(h->d_code_th, code_theta, n_code_theta * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_code_ga, code_gamma, n_code_gamma * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (n_consts > 0) {
+        HIPCHK(h, hipMemcpy(h->d_consts64, consts, n_consts * sizeof(double), hipMemcpyHostToDevice));
+        if (h->cfg.dtype == ROVMPC_F64) {
+            HIPCHK(h, hipMemcpy(h->d_consts, consts, n_consts * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> cf(consts, consts + n_consts);
+            HIPCHK(h, hipMemcpy(h->d_consts, cf.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    // Fingerprint against the compiled-in rows of saved_models/equations_*.csv
+    // (complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3: x15 - x17).
+    bool same = n_features == 18 && !h->cfg.force_interpreter;
+    if (same) {
+        unsigned long long s = 0x9E3779B97F4A7C15ULL;
+        for (int t = 0; t < 16 && same; ++t) {
+            double x[18];
+            for (int i = 0; i < 18; ++i) {
+                s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+                x[i] = ((double)(s >> 11) / 9007199254740992.0) * 6.0 - 3.0;
+            }
+            const double rt = (((sin(x[17]) - sin(x[3])) - x[16]) - x[3]) * 0.048152514;
+            const double rg = x[15] - x[17];
+            const double gt = host_eval(code_theta, n_code_theta, consts, x);
+            const double gg = host_eval(code_gamma, n_code_gamma, consts, x);
+            same = fabs(gt - rt) <= 1e-12 * (1.0 + fabs(rt)) && fabs(gg - rg) <= 1e-12 * (1.0 + fabs(rg));
+        }
+    }
+    h->builtin = same;
+    h->has_model = true;
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!R) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_set_rotation_table: null R");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->cfg.N * 9;
+    if (h->cfg.dtype == ROVMPC_F64) {
+        HIPCHK(h, hipMemcpy(h->d_Rtab, R, n * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> rf(R, R + n);
+        HIPCHK(h, hipMemcpy(h->d_Rtab, rf.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->has_rtab = true;
+    return ROVMPC_OK;
+}
+
+// ---- launches -------------------------------------------------------------------------------
+
+template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<T> &a, const double *d_state,
+                                            const void *d_U, void *d_traj_all) {
+    const rovmpc_config &c = h->cfg;
+    a.U = (const T *)d_U; a.state = d_state; a.code_th = h->d_code_th; a.code_ga = h->d_code_ga;
+    a.consts = (const T *)h->d_consts; a.Rtab = (const T *)h->d_Rtab;
+    a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
+    a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
+    a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
+    a.prev_mode = c.prev_mode; a.integrator = c.integrator;
+    a.h = (T)c.dt; a.vs_h = (T)(c.v_scale * c.dt); a.inv_h = (T)(1.0 / c.dt); a.L = (T)c.L;
+    a.w_per_len = (T)(c.cable_wet_weight / c.L); a.c_lo = (T)c.c_lo; a.c_hi = (T)c.c_hi;
+    a.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
+    a.w_theta = (T)c.w_theta; a.w_gamma = (T)c.w_gamma; a.w_u = (T)c.w_u; a.w_T = (T)c.w_T;
+    a.w_taut = (T)c.w_taut; a.rhoL = (T)(c.rho_taut * c.L); a.w_floor = (T)c.w_floor; a.z_floor = (T)c.z_floor;
+    a.theta_ref = (T)c.theta_ref; a.gamma_ref = (T)c.gamma_ref;
+    for (int i = 0; i < 3; ++i) a.Uref[i] = (T)c.U_ref[i];
+    for (int i = 0; i < 18; ++i) {
+        a.mean[i] = i < h->n_feat ? (T)h->mean[i] : (T)0;
+        a.inv_scale[i] = i < h->n_feat ? (T)(1.0 / h->scale[i]) : (T)1;
+    }
+}
+
+template <typename T, int MODEL, int VT>
+static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, hipStream_t s) {
+    const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL, VT) * sizeof(T);
+    auto kern = rollout_kernel<T, MODEL, VT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(h->NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h, const double *d_state, const void *d_U,
+                                                         void *d_traj_all, hipStream_t s) {
+    RolloutArgs<T> a;
+    fill_args<T>(h, a, d_state, d_U, d_traj_all);
+    const int vt = h->cfg.vt_mode;
+    if (h->builtin) {
+        if (vt == 0) return launch_one<T, MODEL_BUILTIN, 0>(h, a, s);
+        if (vt == 1) return launch_one<T, MODEL_BUILTIN, 1>(h, a, s);
+        return launch_one<T, MODEL_BUILTIN, 2>(h, a, s);
+    }
+    if (vt == 0) return launch_one<T, MODEL_INTERP, 0>(h, a, s);
+    if (vt == 1) return launch_one<T, MODEL_INTERP, 1>(h, a, s);
+    return launch_one<T, MODEL_INTERP, 2>(h, a, s);
+}
+
+static int check_ready(rovmpc_handle *h) {
+    if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
+    if (h->n_feat != 18) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the rollout kernel implements the 18-feature map of simply.py:15-41 (model has %d features)", h->n_feat);
+    if (h->cfg.vt_mode == ROVMPC_VT_TABLE && !h->has_rtab) FAIL(h, ROVMPC_ERR_INVALID, "vt_mode TABLE needs rovmpc_set_rotation_table");
+    return ROVMPC_OK;
+}
+
+static int enqueue_step(rovmpc_handle *h, const double *d_state, const void *d_U, void *d_traj_all, double *d_result,
+                        long long k_offset, long long *d_slots, int rank, int world, hipStream_t s) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    const bool time_it = h->timing && h->ev_used + 2 <= (int)h->ev.size();
+    if (time_it) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], s));
+    hipError_t e = h->cfg.dtype == ROVMPC_F64 ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, s)
+                                              : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, s);
+    if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
+    if (time_it) { HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
+    if (d_result) {
+        if (h->cfg.dtype == ROVMPC_F64)
+            hipLaunchKernelGGL(finalize_kernel<double>, dim3(1), dim3(256), 0, s, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
+                               h->nblocks, (const double *)d_U, h->cfg.N, h->CK, d_result, k_offset, d_slots, rank, world);
+        else
+            hipLaunchKernelGGL(finalize_kernel<float>, dim3(1), dim3(256), 0, s, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
+                               h->nblocks, (const float *)d_U, h->cfg.N, h->CK, d_result, k_offset, d_slots, rank, world);
+        e = hipGetLastError();
+        if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "finalize kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_step_device(rovmpc_handle *h, const double *d_state, const void *d_U, double *d_result, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!d_state || !d_U || !d_result) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device: null pointer");
+    return enqueue_step(h, d_state, d_U, nullptr, d_result, 0, nullptr, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int rovmpc_step_device_sharded(rovmpc_handle *h, const double *d_state, const void *d_U, int64_t k_offset,
+                                          int32_t rank, int32_t world, int64_t *d_slots, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!d_state || !d_U || !d_slots) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device_sharded: null pointer");
+    if (world < 1 || rank < 0 || rank >= world) FAIL(h, ROVMPC_ERR_INVALID, "bad rank/world %d/%d", rank, world);
+    return enqueue_step(h, d_state, d_U, nullptr, h->d_result, k_offset, (long long *)d_slots, rank, world, (hipStream_t)stream);
+}
+
+extern "C" int rovmpc_select_device(rovmpc_handle *h, const int64_t *d_slots, int32_t world, double *d_result, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!d_slots || !d_result || world < 1) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_select_device: bad argument");
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long *)d_slots, world,
+                       rovmpc_result_len(h), d_result);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "select kernel launch failed: %s", hipGetErrorString(e));
+    return ROVMPC_OK;
+}
+
+static int stage_inputs(rovmpc_handle *h, const rovmpc_state *state, const void *U) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_state, state, ROVMPC_STATE_LEN * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_U, U, (size_t)h->cfg.K * h->cfg.N * 3 * h->esz, hipMemcpyHostToDevice, h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_step(rovmpc_handle *h, const rovmpc_state *state, const void *U, double *u_out, double *traj_out,
+                           double *best_cost, int64_t *best_idx) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!state || !U) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step: null state/U");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((rc = stage_inputs(h, state, U))) return rc;
+    if ((rc = enqueue_step(h, h->d_state, h->d_U, nullptr, h->d_result, 0, nullptr, 0, 1, h->stream))) return rc;
+    const size_t R = rovmpc_result_len(h);
+    HIPCHK(h, hipMemcpyAsync(h->h_result, h->d_result, R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (best_cost) *best_cost = h->h_result[0];
+    if (best_idx) *best_idx = (int64_t)h->h_result[1];
+    if (u_out) memcpy(u_out, h->h_result + 2, 3 * sizeof(double));
+    if (traj_out) memcpy(traj_out, h->h_result + 5, 2 * (size_t)(h->cfg.N + 1) * sizeof(double));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_rollout_costs(rovmpc_handle *h, const rovmpc_state *state, const void *U, void *J_out, void *traj_all) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!state || !U || !J_out) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_rollout_costs: null pointer");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((rc = stage_inputs(h, state, U))) return rc;
+    const size_t tbytes = (size_t)h->cfg.K * (h->cfg.N + 1) * 2 * h->esz;
+    if (traj_all && !h->d_traj_all) HIPCHK(h, hipMalloc(&h->d_traj_all, tbytes));
+    if ((rc = enqueue_step(h, h->d_state, h->d_U, traj_all ? h->d_traj_all : nullptr, nullptr, 0, nullptr, 0, 1, h->stream))) return rc;
+    HIPCHK(h, hipMemcpyAsync(J_out, h->d_J, (size_t)h->cfg.K * h->esz, hipMemcpyDeviceToHost, h->stream));
+    if (traj_all) HIPCHK(h, hipMemcpyAsync(traj_all, h->d_traj_all, tbytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+
+extern "C" int rovmpc_timing_enable(rovmpc_handle *h, int32_t max_launches) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (auto &e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear(); h->ev_used = 0; h->timing = max_launches > 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t *count) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    double sum = 0, mn = 1e300;
+    int n = 0;
+    for (int i = 0; i + 1 < h->ev_used; i += 2) {
+        HIPCHK(h, hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        sum += ms; if (ms < mn) mn = ms; ++n;
+    }
+    if (avg_ms) *avg_ms = n ? sum / n : 0.0;
+    if (min_ms) *min_ms = n ? mn : 0.0;
+    if (count) *count = n;
+    h->ev_used = 0;
+    return ROVMPC_OK;
+}
+
+// ---- batched helper mirrors (host pointers, fp64) ---------------------------------------------
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+#define UPLOAD(h, buf, src, bytes)                                                               \
+    do {                                                                                         \
+        HIPCHK(h, (buf).alloc(bytes));                                                           \
+        HIPCHK(h, hipMemcpyAsync((buf).p, (src), (bytes), hipMemcpyHostToDevice, (h)->stream));  \
+    } while (0)
+
+static inline int grid_for(long long n, int bs) { return (int)((n + bs - 1) / bs); }
+
+extern "C" int rovmpc_predict(rovmpc_handle *h, const double *Xs, int64_t n, int32_t which, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
+    if (n < 0 || (n > 0 && (!Xs || !out)) || which < 0 || which > 1) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_predict: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dX, dO;
+    UPLOAD(h, dX, Xs, (size_t)n * h->n_feat * sizeof(double));
+    HIPCHK(h, dO.alloc((size_t)n * sizeof(double)));
+    const int bs = 256;
+    hipLaunchKernelGGL(predict_kernel, dim3(grid_for(n, bs)), dim3(bs), ROVMPC_MAX_STACK * bs * sizeof(double), h->stream,
+                       dX.as<double>(), (long long)n, h->n_feat, which == 0 ? h->d_code_th : h->d_code_ga,
+                       which == 0 ? h->n_th : h->n_ga, h->d_consts64, dO.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *time, int64_t T, double theta0, double gamma0,
+                             int32_t integrator, double *theta_out, double *gamma_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
+    if (T < 1 || !Xs || !time || (integrator != ROVMPC_RK4 && integrator != ROVMPC_EULER))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_replay: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dX, dT, dIt, dIg, dOt, dOg;
+    UPLOAD(h, dX, Xs, (size_t)T * h->n_feat * sizeof(double));
+    UPLOAD(h, dT, time, (size_t)T * sizeof(double));
+    HIPCHK(h, dIt.alloc((size_t)T * sizeof(double)));
+    HIPCHK(h, dIg.alloc((size_t)T * sizeof(double)));
+    HIPCHK(h, dOt.alloc((size_t)T * sizeof(double)));
+    HIPCHK(h, dOg.alloc((size_t)T * sizeof(double)));
+    if (T > 1) {
+        const int bs = 128;
+        const size_t lds = (size_t)(h->n_feat + ROVMPC_MAX_STACK) * bs * sizeof(double);
+        hipLaunchKernelGGL(replay_increments_kernel, dim3(grid_for(T - 1, bs)), dim3(bs), lds, h->stream, dX.as<double>(),
+                           dT.as<double>(), (long long)T, h->n_feat, h->d_code_th, h->n_th, h->d_code_ga, h->n_ga,
+                           h->d_consts64, integrator, dIt.as<double>(), dIg.as<double>());
+        HIPCHK(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(replay_cumsum_kernel, dim3(1), dim3(64), 0, h->stream, dIt.as<double>(), dIg.as<double>(), (long long)T,
+                       theta0, gamma0, dOt.as<double>(), dOg.as<double>());
+    HIPCHK(h, hipGetLastError());
+    if (theta_out) HIPCHK(h, hipMemcpyAsync(theta_out, dOt.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (gamma_out) HIPCHK(h, hipMemcpyAsync(gamma_out, dOg.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_solve_catenary(rovmpc_handle *h, const double *l, const double *dH, double L, int64_t n, double *C_out,
+                                     double *T_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!l || !dH || !C_out))) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_solve_catenary: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dl, dh, dC, dT;
+    UPLOAD(h, dl, l, (size_t)n * sizeof(double));
+    UPLOAD(h, dh, dH, (size_t)n * sizeof(double));
+    HIPCHK(h, dC.alloc((size_t)n * sizeof(double)));
+    HIPCHK(h, dT.alloc((size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(solve_catenary_kernel, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, dl.as<double>(), dh.as<double>(), L,
+                       h->cfg.c_lo, h->cfg.c_hi, h->cfg.cable_wet_weight / L, (long long)n, dC.as<double>(),
+                       T_out ? dT.as<double>() : nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(C_out, dC.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (T_out) HIPCHK(h, hipMemcpyAsync(T_out, dT.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_rodrigues(rovmpc_handle *h, const double *v, const double *axis, const double *angle, int64_t n, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!v || !axis || !angle || !out))) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_rodrigues: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dv, da, dg, dout;
+    UPLOAD(h, dv, v, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, da, axis, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, dg, angle, (size_t)n * sizeof(double));
+    HIPCHK(h, dout.alloc((size_t)n * 3 * sizeof(double)));
+    hipLaunchKernelGGL(rodrigues_kernel, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, dv.as<double>(), da.as<double>(),
+                       dg.as<double>(), (long long)n, dout.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dout.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_catenary_points(rovmpc_handle *h, const double *A, const double *B, double L, int64_t n, int32_t M,
+                                      double *pts, int32_t *valid, double *params) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || M < 2 || (n > 0 && (!A || !B || !pts || !valid))) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_catenary_points: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dA, dB, dP, dV, dQ;
+    UPLOAD(h, dA, A, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, dB, B, (size_t)n * 3 * sizeof(double));
+    HIPCHK(h, dP.alloc((size_t)n * M * 3 * sizeof(double)));
+    HIPCHK(h, dV.alloc((size_t)n * sizeof(int32_t)));
+    HIPCHK(h, dQ.alloc((size_t)n * 3 * sizeof(double)));
+    const double up = h->cfg.frame == ROVMPC_ENU ? 1.0 : -1.0;
+    hipLaunchKernelGGL(catenary_points_kernel, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, dA.as<double>(), dB.as<double>(), L,
+                       up, h->cfg.c_lo, h->cfg.c_hi, (long long)n, M, dP.as<double>(), dV.as<int32_t>(), dQ.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(pts, dP.p, (size_t)n * M * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(valid, dV.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (params) HIPCHK(h, hipMemcpyAsync(params, dQ.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B, const double *theta,
+                                         const double *gamma, double L, int64_t n, int32_t M, double *out, int32_t *npts,
+                                         double *z_low) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || M < 2 || (n > 0 && (!A || !B || !theta || !gamma || !out || !npts)))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_transform_catenary: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dA, dB, dt, dg, dO, dN, dZ;
+    UPLOAD(h, dA, A, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, dB, B, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, dt, theta, (size_t)n * sizeof(double));
+    UPLOAD(h, dg, gamma, (size_t)n * sizeof(double));
+    const size_t ob = (size_t)4 * n * M * 3 * sizeof(double);
+    HIPCHK(h, dO.alloc(ob));
+    HIPCHK(h, dN.alloc((size_t)n * 2 * sizeof(int32_t)));
+    HIPCHK(h, dZ.alloc((size_t)n * sizeof(double)));
+    const double up = h->cfg.frame == ROVMPC_ENU ? 1.0 : -1.0;
+    hipLaunchKernelGGL(transform_catenary_kernel, dim3(grid_for(n, 128)), dim3(128), 0, h->stream, dA.as<double>(), dB.as<double>(),
+                       dt.as<double>(), dg.as<double>(), L, up, h->cfg.c_lo, h->cfg.c_hi, (long long)n, M, dO.as<double>(),
+                       dN.as<int32_t>(), dZ.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dO.p, ob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(npts, dN.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (z_low) HIPCHK(h, hipMemcpyAsync(z_low, dZ.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, const double *v, int64_t n, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!R || !v || !out))) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_velocity_transform: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dR, dv, dout;
+    UPLOAD(h, dR, R, (size_t)n * 9 * sizeof(double));
+    UPLOAD(h, dv, v, (size_t)n * 3 * sizeof(double));
+    HIPCHK(h, dout.alloc((size_t)n * 3 * sizeof(double)));
+    hipLaunchKernelGGL(velocity_transform_kernel, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, dR.as<double>(), dv.as<double>(),
+                       (long long)n, dout.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dout.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}

@@ -1,0 +1,206 @@
+// util_kernels.h -- batched mirrors of the reference's per-row helpers (fp64, gfx950).
+// Each kernel replaces a Python loop of the reference; see include/rovmpc.h for the map.
+#pragma once
+#include "rollout_kernels.h"
+
+namespace rovmpc {
+
+// model.predict(X) on n already-scaled rows: one lane per row, operand stack in LDS.
+__global__ void __launch_bounds__(256)
+predict_kernel(const double *__restrict__ Xs, long long n, int F, const int32_t *code, int ncode,
+               const double *consts, double *out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    double *stack = reinterpret_cast<double *>(smem_raw) + threadIdx.x;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long row = i < n ? i : n - 1;            // keep control flow uniform
+    const double v = interp_eval<double>(code, ncode, consts, Xs + row * F, 1, stack, blockDim.x);
+    if (i < n) out[i] = v;
+}
+
+// Increments of rk4_integration (simulate_rk4_theta_gamma.py:56-66) / integrate_theta_gamma
+// (main_fun.py:757-762) for step i = 1..T-1, both expressions.  inc[0] is unused.
+__global__ void __launch_bounds__(128)
+replay_increments_kernel(const double *__restrict__ Xs, const double *__restrict__ time, long long T, int F,
+                         const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
+                         const double *consts, int integrator, double *inc_th, double *inc_ga) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int NT = blockDim.x;
+    double *feat = reinterpret_cast<double *>(smem_raw) + threadIdx.x;          // [F][lane]
+    double *stack = reinterpret_cast<double *>(smem_raw) + (size_t)F * NT + threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * NT + threadIdx.x + 1;
+    const long long i = i0 < T ? i0 : T - 1;
+    const double dt = time[i] - time[i - 1];
+    const double *x0 = Xs + (i - 1) * F, *x1 = Xs + i * F;
+    double it, ig;
+    {
+        const double k1t = interp_eval<double>(code_th, n_th, consts, x0, 1, stack, NT);
+        const double k1g = interp_eval<double>(code_ga, n_ga, consts, x0, 1, stack, NT);
+        if (integrator == ROVMPC_EULER) {
+            it = k1t * dt; ig = k1g * dt;
+        } else {
+            for (int f = 0; f < F; ++f) feat[(size_t)f * NT] = (x0[f] + x1[f]) / 2;   // :62-63
+            const double k2t = interp_eval<double>(code_th, n_th, consts, feat, NT, stack, NT);
+            const double k2g = interp_eval<double>(code_ga, n_ga, consts, feat, NT, stack, NT);
+            const double k4t = interp_eval<double>(code_th, n_th, consts, x1, 1, stack, NT);
+            const double k4g = interp_eval<double>(code_ga, n_ga, consts, x1, 1, stack, NT);
+            it = (dt / 6) * (k1t + 2 * k2t + 2 * k2t + k4t);                          // :66
+            ig = (dt / 6) * (k1g + 2 * k2g + 2 * k2g + k4g);
+        }
+    }
+    if (i0 < T) { inc_th[i0] = it; inc_ga[i0] = ig; }
+}
+
+// y[i] = y[i-1] + inc[i] in the reference's (sequential) order; two lanes, one per series.
+__global__ void __launch_bounds__(64)
+replay_cumsum_kernel(const double *inc_th, const double *inc_ga, long long T, double th0, double ga0,
+                     double *th_out, double *ga_out) {
+    const int w = threadIdx.x;
+    if (w > 1) return;
+    const double *inc = w == 0 ? inc_th : inc_ga;
+    double *out = w == 0 ? th_out : ga_out;
+    if (!out) return;
+    double y = w == 0 ? th0 : ga0;
+    out[0] = y;
+    for (long long i = 1; i < T; ++i) { y = y + inc[i]; out[i] = y; }
+}
+
+__global__ void __launch_bounds__(256)
+solve_catenary_kernel(const double *l, const double *dH, double L, double c_lo, double c_hi,
+                      double w_per_len, long long n, double *C_out, double *T_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double C = solve_catenary_C<double>(l[i], dH[i], L, c_lo, c_hi);
+    C_out[i] = C;
+    if (T_out) T_out[i] = cable_tension<double>(l[i], C, w_per_len);
+}
+
+// main_fun.py:18-35 with the axis normalisation of :30.
+RV_DEV V3<double> rodrigues_ref(V3<double> v, V3<double> axis, double ang) {
+    const double inv = 1.0 / m_sqrt(dot3(axis, axis));
+    const V3<double> k = {axis.x * inv, axis.y * inv, axis.z * inv};
+    double s, c;
+    m_sincos(ang, &s, &c);
+    return rodrigues_unit(v, k, s, c);
+}
+
+__global__ void __launch_bounds__(256)
+rodrigues_kernel(const double *v, const double *axis, const double *ang, long long n, double *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3<double> r = rodrigues_ref({v[3 * i], v[3 * i + 1], v[3 * i + 2]},
+                                       {axis[3 * i], axis[3 * i + 1], axis[3 * i + 2]}, ang[i]);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+
+// Catenary(length=L)(a, b)[3]: M samples, uniform in the horizontal coordinate, of
+// z = (cosh(C (x - x0)) - cosh(C x0)) / C in the vertical plane through a, b
+// (catenary_model.py:10-12 shape law, C from main_fun.py:418-431).  Returns false when the
+// reference's catenary_fn would return None at [3].
+RV_DEV bool catenary_params(V3<double> rel, double L, double up, double c_lo, double c_hi,
+                            double &l, double &C, double &x0, double &ch0) {
+    l = m_sqrt(rel.x * rel.x + rel.y * rel.y);
+    const double dH = up * rel.z;
+    C = solve_catenary_C<double>(l, dH, L, c_lo, c_hi);
+    if (!(C == C)) return false;
+    x0 = 0.5 * l - m_atanh(dH / L) / C;
+    ch0 = m_cosh(C * x0);
+    return true;
+}
+
+RV_DEV V3<double> catenary_point(V3<double> a, V3<double> rel, double l, double C, double x0, double ch0,
+                                 double up, int j, int M) {
+    const double t = (double)j / (double)(M - 1);
+    const double s = (m_cosh(C * (l * t - x0)) - ch0) / C;
+    return {a.x + t * rel.x, a.y + t * rel.y, a.z + up * s};
+}
+
+__global__ void __launch_bounds__(256)
+catenary_points_kernel(const double *A, const double *B, double L, double up, double c_lo, double c_hi,
+                       long long n, int M, double *pts, int32_t *valid, double *params) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3<double> a = {A[3 * i], A[3 * i + 1], A[3 * i + 2]};
+    const V3<double> rel = {B[3 * i] - a.x, B[3 * i + 1] - a.y, B[3 * i + 2] - a.z};
+    double l, C, x0, ch0;
+    const bool ok = catenary_params(rel, L, up, c_lo, c_hi, l, C, x0, ch0);
+    valid[i] = ok ? 1 : 0;
+    const double nan = m_nan<double>();
+    if (params) {
+        params[3 * i] = ok ? C : nan;
+        params[3 * i + 1] = ok ? (ch0 - 1.0) / C : nan;
+        params[3 * i + 2] = ok ? x0 : nan;
+    }
+    double *p = pts + (size_t)i * M * 3;
+    for (int j = 0; j < M; ++j) {
+        V3<double> q = ok ? catenary_point(a, rel, l, C, x0, ch0, up, j, M) : V3<double>{nan, nan, nan};
+        p[3 * j] = q.x; p[3 * j + 1] = q.y; p[3 * j + 2] = q.z;
+    }
+}
+
+// transform_catenary (main_fun.py:38-111) for n cases, one lane per case, the reference's
+// two Rodrigues calls per point kept as they are (this is the full-shape path; the rollout
+// kernel only needs the lowest z and uses the composed row instead).
+__global__ void __launch_bounds__(128)
+transform_catenary_kernel(const double *A, const double *B, const double *theta, const double *gamma,
+                          double L, double up, double c_lo, double c_hi, long long n, int M,
+                          double *out, int32_t *npts, double *z_low) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nan = m_nan<double>();
+    const V3<double> a = {A[3 * i], A[3 * i + 1], A[3 * i + 2]};
+    const V3<double> b = {B[3 * i], B[3 * i + 1], B[3 * i + 2]};
+    const V3<double> rel = {b.x - a.x, b.y - a.y, b.z - a.z};
+    const double th = theta[i], ga = gamma[i];
+    const size_t plane = (size_t)n * M * 3;
+    double *o0 = out + (size_t)i * M * 3, *o1 = o0 + plane, *o2 = o1 + plane, *o3 = o2 + plane;
+    auto put = [&](double *o, int j, V3<double> q) { o[3 * j] = q.x; o[3 * j + 1] = q.y; o[3 * j + 2] = q.z; };
+
+    // Step 1: original catenary (:72)
+    double l, C, x0, ch0;
+    const bool ok0 = catenary_params(rel, L, up, c_lo, c_hi, l, C, x0, ch0);
+    const int n0 = ok0 ? M : 2;
+    for (int j = 0; j < M; ++j) {
+        V3<double> q = {nan, nan, nan};
+        if (ok0) q = catenary_point(a, rel, l, C, x0, ch0, up, j, M);
+        else if (j == 0) q = a; else if (j == 1) q = b;
+        put(o0, j, q);
+    }
+    // Step 2: axes (:75-89)
+    V3<double> kt, kg;
+    theta_gamma_axes<double>(rel, kt, kg);
+    // Step 3: rotated end point and its catenary (:92-93)
+    const V3<double> rb = rodrigues_ref(rel, kt, th);
+    const V3<double> Bp = {a.x + rb.x, a.y + rb.y, a.z + rb.z};
+    const bool ok1 = catenary_params(rb, L, up, c_lo, c_hi, l, C, x0, ch0);
+    const int n1 = ok1 ? M : 2;
+    double best = m_inf<double>();
+    for (int j = 0; j < M; ++j) {
+        V3<double> q = {nan, nan, nan}, q2 = q, q3 = q;
+        if (j < n1) {
+            if (ok1) q = catenary_point(a, rb, l, C, x0, ch0, up, j, M);
+            else q = (j == 0) ? a : Bp;
+            // Step 4 (:96-99) and Step 6 (:106-109)
+            const V3<double> r2 = rodrigues_ref({q.x - a.x, q.y - a.y, q.z - a.z}, kt, -th);
+            q2 = {a.x + r2.x, a.y + r2.y, a.z + r2.z};
+            const V3<double> r3 = rodrigues_ref({q2.x - a.x, q2.y - a.y, q2.z - a.z}, kg, ga);
+            q3 = {a.x + r3.x, a.y + r3.y, a.z + r3.z};
+            const double zz = up * q3.z;
+            best = (zz != zz) ? zz : (zz < best ? zz : best);
+        }
+        put(o1, j, q); put(o2, j, q2); put(o3, j, q3);
+    }
+    npts[2 * i] = n0; npts[2 * i + 1] = n1;
+    if (z_low) z_low[i] = up * best;                      // fully_augmented_catenary.py:21-22
+}
+
+__global__ void __launch_bounds__(256)
+velocity_transform_kernel(const double *R, const double *v, long long n, double *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *r = R + 9 * i, *u = v + 3 * i;
+    out[3 * i] = r[0] * u[0] + r[1] * u[1] + r[2] * u[2];
+    out[3 * i + 1] = r[3] * u[0] + r[4] * u[1] + r[5] * u[2];
+    out[3 * i + 2] = r[6] * u[0] + r[7] * u[1] + r[8] * u[2];
+}
+
+}  // namespace rovmpc

@@ -1,0 +1,34 @@
+"""Host-side feature map of generation 1 (simply.py:15-41; main_fun.py:167-193 is the same
+without the two ``_prev`` columns).  Off the hot path: inside the rollout the same rows are
+built per (candidate, node) by the HIP kernel."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def extract_features_arrays(P0, P1, V1, time, theta, gamma, with_prev: bool = True) -> np.ndarray:
+    """P0, P1 in metres (the reference divides its mm columns by 1000 first), V1 raw."""
+    P0 = np.asarray(P0, float); P1 = np.asarray(P1, float); V1 = np.asarray(V1, float)
+    time = np.asarray(time, float)
+    A1 = np.stack([np.gradient(V1[:, j], time) for j in range(3)], axis=1)
+    rel_vec = P1 - P0
+    nr = np.linalg.norm(rel_vec, axis=1, keepdims=True)
+    unit_rel = rel_vec / (nr + 1e-8)
+    tension = np.clip(nr, 1e-5, 10)
+    angle_proj = np.clip(np.sum(V1 * unit_rel, axis=1, keepdims=True)
+                         / (np.linalg.norm(V1, axis=1, keepdims=True) + 1e-8), -1, 1)
+    theta = np.asarray(theta, float).reshape(-1, 1); gamma = np.asarray(gamma, float).reshape(-1, 1)
+    cols = [P1, V1, A1, unit_rel, tension, angle_proj, theta, gamma]
+    if with_prev:
+        tp = np.roll(theta, 1); gp = np.roll(gamma, 1)
+        tp[0] = theta[0]; gp[0] = gamma[0]
+        cols += [tp, gp]
+    return np.hstack(cols)
+
+
+def extract_features(df, with_prev: bool = True) -> np.ndarray:
+    """Same column names as the reference's data frames (simply.py:16-19)."""
+    P0 = df[["rod_end X", "rod_end Y", "rod_end Z"]].values / 1000
+    P1 = df[["robot_cable_attach_point X", "robot_cable_attach_point Y", "robot_cable_attach_point Z"]].values / 1000
+    V1 = df[["rob_cor_speed X", "rob_cor_speed Y", "rob_cor_speed Z"]].values
+    return extract_features_arrays(P0, P1, V1, df["Time"].values, df["Theta"].values, df["Gamma"].values, with_prev)

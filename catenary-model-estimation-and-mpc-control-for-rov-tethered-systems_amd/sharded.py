@@ -1,0 +1,120 @@
+"""Candidate-sharded MPC step: one process per GPU, K/G candidates per rank, ONE
+all-reduce(min) per step over xGMI (RCCL through ``torch.distributed``, backend "nccl").
+
+Protocol: every rank maps its local result record
+[J*, k*, u(3), (theta,gamma)_0..N] to order-preserving int64 keys and writes them into row
+``rank`` of a [world][R] buffer whose other rows are INT64_MAX; after all-reduce(min) every
+rank holds every rank's record and takes the lexicographic (cost, global index) minimum,
+which is exactly ``np.argmin`` over the un-sharded candidate set.  No other collective.
+
+``pack_record`` / ``select_record`` are the host (torch, any device) statement of the two tiny
+kernels ``finalize_kernel`` / ``select_kernel``; the gloo CPU tests run them, the GPU path
+runs the kernels.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+INT64_MAX = np.iinfo(np.int64).max
+_LOW63 = 0x7FFFFFFFFFFFFFFF
+
+
+def ordered_keys(x: torch.Tensor) -> torch.Tensor:
+    """float64 -> int64 keys whose signed order equals the IEEE order of the values."""
+    b = x.contiguous().view(torch.int64)
+    return b ^ ((b >> 63) & _LOW63)
+
+
+def ordered_values(k: torch.Tensor) -> torch.Tensor:
+    b = k ^ ((k >> 63) & _LOW63)
+    return b.contiguous().view(torch.float64)
+
+
+def pack_record(record: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """[world][R] int64 slots: own row = keys of ``record`` (float64, R), others INT64_MAX."""
+    R = record.numel()
+    slots = torch.full((world, R), INT64_MAX, dtype=torch.int64, device=record.device)
+    slots[rank] = ordered_keys(record.to(torch.float64))
+    return slots
+
+
+def select_record(slots: torch.Tensor) -> torch.Tensor:
+    """Lexicographic (cost, index) minimum over the rows of the reduced slot buffer."""
+    vals = ordered_values(slots)
+    best = 0
+    for r in range(1, vals.shape[0]):
+        if vals[r, 0] < vals[best, 0] or (vals[r, 0] == vals[best, 0] and vals[r, 1] < vals[best, 1]):
+            best = r
+    return vals[best].clone()
+
+
+def shard_bounds(K_total: int, rank: int, world: int):
+    """Contiguous K/G slice of rank (the last ranks take the remainder one each)."""
+    base, rem = divmod(K_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedMPC:
+    """Per-rank driver.  GPU path: ``Engine`` + torch CUDA tensors + nccl.  The ``local_solver``
+    hook exists so the host logic can be exercised with gloo on CPU in tests; it must return
+    the local record (float64 tensor of length R with a GLOBAL index in [1])."""
+
+    def __init__(self, engine=None, rank: Optional[int] = None, world: Optional[int] = None,
+                 K_total: Optional[int] = None, local_solver: Optional[Callable] = None, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.engine = engine
+        self.local_solver = local_solver
+        if engine is None and local_solver is None:
+            raise ValueError("ShardedMPC needs an Engine (GPU) or a local_solver")
+        if engine is not None:
+            K_local = engine.cfg.K
+            self.K_total = K_total if K_total is not None else K_local * self.world
+            self.k_offset = shard_bounds(self.K_total, self.rank, self.world)[0]
+            dev = torch.device("cuda", engine.cfg.device)
+            self.R = engine.result_len
+            # double-buffered slots / results so step i's collective can overlap step i+1's rollout
+            self.slots = [torch.empty((self.world, self.R), dtype=torch.int64, device=dev) for _ in range(2)]
+            self.results = [torch.empty(self.R, dtype=torch.float64, device=dev) for _ in range(2)]
+            self.comm_stream = torch.cuda.Stream(device=dev)
+            self._flip = 0
+
+    # -- GPU path ----------------------------------------------------------------------------
+    def step_device(self, d_state: torch.Tensor, d_U: torch.Tensor) -> torch.Tensor:
+        """Enqueue one sharded step; returns the device tensor that will hold the global
+        record.  The rollout runs on the current stream, the all-reduce and the select on a
+        side stream, so consecutive independent steps overlap compute with the collective."""
+        eng = self.engine
+        i = self._flip
+        self._flip ^= 1
+        cur = torch.cuda.current_stream()
+        # the side stream may still be reading slots[i] from two steps ago
+        cur.wait_stream(self.comm_stream)
+        eng.step_device_sharded(d_state.data_ptr(), d_U.data_ptr(), self.k_offset, self.rank, self.world,
+                                self.slots[i].data_ptr(), cur.cuda_stream)
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            if self.world > 1:
+                self.dist.all_reduce(self.slots[i], op=self.dist.ReduceOp.MIN, group=self.group)
+            eng.select_device(self.slots[i].data_ptr(), self.world, self.results[i].data_ptr(),
+                              self.comm_stream.cuda_stream)
+        return self.results[i]
+
+    def synchronize(self):
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        torch.cuda.current_stream().synchronize()
+
+    # -- host-logic path (tests, gloo) ---------------------------------------------------------
+    def step_host(self, *solver_args) -> torch.Tensor:
+        record = self.local_solver(*solver_args)
+        slots = pack_record(record, self.rank, self.world)
+        if self.world > 1:
+            self.dist.all_reduce(slots, op=self.dist.ReduceOp.MIN, group=self.group)
+        return select_record(slots)

@@ -1,0 +1,214 @@
+/*
+ * rovmpc.h -- C ABI of librovmpc.so: the MI355X (gfx950) batched MPC rollout engine for
+ * the tether (theta, gamma) state of a tethered ROV.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference project
+ * (eather0056/Catenary-Model-Estimation-and-MPC-Control-for-ROV-Tethered-Systems).  The
+ * reference is pure Python; every entry point below names the Python callable (file:line,
+ * relative to the reference root) whose per-row loop it replaces.  The binding a
+ * maintainer of the reference would add is a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns ROVMPC_OK (0) or a negative ROVMPC_ERR_* code and never throws;
+ *    rovmpc_last_error() gives the message of the last failure on that handle
+ *    (or of the last failed rovmpc_create when passed NULL);
+ *  - all buffers are caller-owned and C-contiguous.  Functions without a `_device` suffix
+ *    take HOST pointers and stage H2D/D2H themselves (blocking).  `_device` functions take
+ *    DEVICE pointers plus a hipStream_t (as void*), enqueue asynchronously and do not
+ *    synchronise;
+ *  - "real" buffers (U, J, traj_all) are double when cfg.dtype == ROVMPC_F64 and float when
+ *    ROVMPC_F32; state, results and the geometry helpers are always double;
+ *  - one handle = one device + one internal stream + one workspace; a handle is NOT
+ *    thread-safe, distinct handles are independent;
+ *  - numeric failure is reported in-band as NaN exactly where the reference yields NaN
+ *    (solve_catenary: no sign change on the bracket).
+ */
+#ifndef ROVMPC_H
+#define ROVMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROVMPC_OK               0
+#define ROVMPC_ERR_INVALID     -1   /* bad argument / configuration                        */
+#define ROVMPC_ERR_HIP         -2   /* a HIP runtime call failed (no GPU, OOM, ...)        */
+#define ROVMPC_ERR_NO_MODEL    -3   /* rovmpc_set_model has not been called                */
+#define ROVMPC_ERR_UNSUPPORTED -4   /* valid request this build cannot serve               */
+
+#define ROVMPC_F64 0
+#define ROVMPC_F32 1
+
+#define ROVMPC_VT_NONE    0   /* candidate controls already are rob_cor_speed              */
+#define ROVMPC_VT_COMPOSE 1   /* v_cat = R_theta(+theta) R_gamma(-gamma) v_world per step  */
+#define ROVMPC_VT_TABLE   2   /* v_cat = R[n] v_world, R supplied per horizon step         */
+
+#define ROVMPC_PREV_INTERP 0  /* delay slots x16,x17 follow the reference's row midpoint   */
+#define ROVMPC_PREV_HOLD   1  /* delay slots held at the previous node for all RK4 stages  */
+
+#define ROVMPC_RK4   0        /* simulate_rk4_theta_gamma.py:52-68                         */
+#define ROVMPC_EULER 1        /* main_fun.py:735-764                                       */
+
+#define ROVMPC_ENU 0
+#define ROVMPC_NED 1
+
+#define ROVMPC_MAX_FEATURES 32
+#define ROVMPC_MAX_CODE     256
+#define ROVMPC_MAX_STACK    16
+#define ROVMPC_STATE_LEN    16
+
+/* Bytecode of one symbolic expression: postfix, one int32 per instruction,
+ * (arg << 8) | opcode.  arg = feature index (PUSH_F), constant index (PUSH_C) or integer
+ * exponent (POWI).  Operator vocabulary = every operator the reference's PySR runs use
+ * (simply.py:65-66, PySRTrainingScript.py:53-54, cluster_run/train_dynamics.py:28-46,
+ * dynamic_eq_theta_cluster.py:35-43). */
+enum rovmpc_opcode {
+    ROVMPC_OP_PUSH_C = 0, ROVMPC_OP_PUSH_F = 1,
+    ROVMPC_OP_ADD = 2, ROVMPC_OP_SUB = 3, ROVMPC_OP_MUL = 4, ROVMPC_OP_DIV = 5,
+    ROVMPC_OP_NEG = 6, ROVMPC_OP_SIN = 7, ROVMPC_OP_COS = 8, ROVMPC_OP_TANH = 9,
+    ROVMPC_OP_ABS = 10, ROVMPC_OP_SQUARE = 11, ROVMPC_OP_EXP = 12, ROVMPC_OP_LOG = 13,
+    ROVMPC_OP_SQRT = 14, ROVMPC_OP_POW = 15, ROVMPC_OP_POWI = 16,
+    ROVMPC_OP_SAFE_LOG = 17,   /* log(|x| + 1e-5)  */
+    ROVMPC_OP_SAFE_SQRT = 18,  /* sqrt(|x|)        */
+    ROVMPC_OP_COUNT = 19
+};
+
+typedef struct rovmpc_config {
+    int32_t struct_size;        /* = sizeof(rovmpc_config), ABI check                       */
+    int32_t device;             /* HIP device ordinal                                       */
+    int32_t dtype;              /* ROVMPC_F64 | ROVMPC_F32                                  */
+    int32_t N;                  /* horizon steps                                            */
+    int32_t K;                  /* candidates per step on this handle (this shard)          */
+    int32_t n_shape_pts;        /* M samples of the augmented catenary per node (>= 2)      */
+    int32_t vt_mode;            /* ROVMPC_VT_*                                              */
+    int32_t prev_mode;          /* ROVMPC_PREV_*                                            */
+    int32_t integrator;         /* ROVMPC_RK4 | ROVMPC_EULER                                */
+    int32_t frame;              /* ROVMPC_ENU | ROVMPC_NED (catenary.py:10)                 */
+    int32_t force_interpreter;  /* 1: never take the compiled-in default-equation path      */
+    int32_t candidates_per_block; /* 0 = auto; else 1..64                                   */
+    double dt;                  /* horizon step [s]                                         */
+    double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
+    double L;                   /* cable length [m] (test_cluster.py:22)                    */
+    double cable_wet_weight;    /* [N] (test_cluster.py:23)                                 */
+    double c_lo, c_hi;          /* brentq bracket of main_fun.py:425 (1e-6, 10)             */
+    double w_theta, w_gamma, w_u, w_T, w_taut, rho_taut, w_floor, z_floor;
+    double theta_ref, gamma_ref;
+    double U_ref[3];
+} rovmpc_config;
+
+/* 16 doubles: P0[3] anchor (rod_end, m), P1[3] ROV attach point (m), V1[3] current
+ * rob_cor_speed, A1[3] current acceleration feature, theta, gamma, theta_prev, gamma_prev
+ * (feature slots x0..x8, x14..x17 of simply.py:41 at horizon node 0). */
+typedef struct rovmpc_state {
+    double P0[3], P1[3], V1[3], A1[3];
+    double theta, gamma, theta_prev, gamma_prev;
+} rovmpc_state;
+
+typedef struct rovmpc_handle rovmpc_handle;
+
+const char *rovmpc_version(void);
+void rovmpc_default_config(rovmpc_config *cfg);
+
+int  rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out);
+void rovmpc_destroy(rovmpc_handle *h);
+const char *rovmpc_last_error(const rovmpc_handle *h);
+
+/* Learned dynamics = saved_models/scaler.pkl (mean_, scale_) + one row of
+ * saved_models/equations_dtheta_dt.csv and one of equations_dgamma_dt.csv compiled to
+ * bytecode by the host (replaces PySRRegressor.predict on those rows). */
+int rovmpc_set_model(rovmpc_handle *h, int32_t n_features,
+                     const double *mean, const double *scale,
+                     const int32_t *code_theta, int32_t n_code_theta,
+                     const int32_t *code_gamma, int32_t n_code_gamma,
+                     const double *consts, int32_t n_consts);
+
+/* ROVMPC_VT_TABLE only: R[N][3][3] row-major, rows [exc1 eyc1 ezc1; exc2 ..; exc3 ..]
+ * (batch_correct_velocity.py:38-45). */
+int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R);
+
+/* ---- the hot path ---------------------------------------------------------------------
+ * One MPC step: roll every candidate control sequence U[K][N][3] over the horizon
+ * (closed-loop RK4 of the learned dtheta/dt, dgamma/dt -- simulate_rk4_theta_gamma.py:52-68
+ * generalised to feed the state back; catenary parameter/tension -- main_fun.py:418-431,
+ * 302-305; theta/gamma-augmented catenary lowest point -- main_fun.py:38-111,
+ * fully_augmented_catenary.py:21-22; velocity transform -- velocity_transform_batch.py:
+ * 100-101), accumulate the cost, arg-min with np.argmin tie-break.
+ * u_out[3] = U[k*][0][:], traj_out[(N+1)][2] = predicted (theta, gamma) of k*. */
+int rovmpc_step(rovmpc_handle *h, const rovmpc_state *state, const void *U,
+                double *u_out, double *traj_out, double *best_cost, int64_t *best_idx);
+
+/* Parity/debug: all K costs (and, if traj_all != NULL, all K trajectories [K][N+1][2]). */
+int rovmpc_rollout_costs(rovmpc_handle *h, const rovmpc_state *state, const void *U,
+                         void *J_out, void *traj_all);
+
+/* Result record length in doubles: 5 + 2 (N+1):
+ * [J*, k* (as double), u[3], theta_0, gamma_0, ..., theta_N, gamma_N]. */
+int32_t rovmpc_result_len(const rovmpc_handle *h);
+
+/* Device-resident, asynchronous flavour: d_state = 16 doubles, d_U = K*N*3 reals,
+ * d_result = rovmpc_result_len doubles, all in device memory; stream = hipStream_t. */
+int rovmpc_step_device(rovmpc_handle *h, const double *d_state, const void *d_U,
+                       double *d_result, void *stream);
+
+/* Candidate-sharded step (one handle per rank): writes this rank's record, order-preserving
+ * mapped to int64 (k* offset by k_offset), into d_slots[world][result_len] with every
+ * other rank's row = INT64_MAX, so that ONE all-reduce(min) over the buffer assembles all
+ * ranks' records on every rank.  rovmpc_select_device then takes the lexicographic
+ * (cost, index) minimum -- identical to a single np.argmin over all shards. */
+int rovmpc_step_device_sharded(rovmpc_handle *h, const double *d_state, const void *d_U,
+                               int64_t k_offset, int32_t rank, int32_t world,
+                               int64_t *d_slots, void *stream);
+int rovmpc_select_device(rovmpc_handle *h, const int64_t *d_slots, int32_t world,
+                         double *d_result, void *stream);
+
+/* Per-launch timing of the rollout kernel with HIP events on the launch stream. */
+int rovmpc_timing_enable(rovmpc_handle *h, int32_t max_launches);
+int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t *count);
+
+/* ---- batched mirrors of the reference's per-row helpers (host pointers) ---------------- */
+
+/* model.predict(X(n,F)) for the loaded theta (which=0) / gamma (which=1) expression;
+ * X is what the reference feeds its models: already-scaled feature rows. */
+int rovmpc_predict(rovmpc_handle *h, const double *Xs, int64_t n, int32_t which, double *out);
+
+/* rk4_integration(model, x_input, time, y0) (simulate_rk4_theta_gamma.py:52-68) when
+ * integrator == ROVMPC_RK4, integrate_theta_gamma (main_fun.py:735-764) when ROVMPC_EULER;
+ * both expressions in one call, either output may be NULL.  Xs[T][F] scaled rows. */
+int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *time, int64_t T,
+                  double theta0, double gamma0, int32_t integrator,
+                  double *theta_out, double *gamma_out);
+
+/* solve_catenary(l, delta_H, L) (main_fun.py:418-431) and, if T_out != NULL, the tension
+ * rule of main_fun.py:302-305 with cfg.cable_wet_weight. */
+int rovmpc_solve_catenary(rovmpc_handle *h, const double *l, const double *delta_H, double L,
+                          int64_t n, double *C_out, double *T_out);
+
+/* rodrigues_rotation(vector, axis, angle_rad) (main_fun.py:18-35), n rows. */
+int rovmpc_rodrigues(rovmpc_handle *h, const double *v, const double *axis,
+                     const double *angle, int64_t n, double *out);
+
+/* Catenary(length=L, reference_frame=cfg.frame)(a, b) (catenary.py:10,25-29) for n pairs:
+ * pts[n][M][3]; valid[n] = 0 where the reference's catenary_fn would return None at [3]
+ * (then pts row = NaN); params[n][3] = (C, sag, x_low). */
+int rovmpc_catenary_points(rovmpc_handle *h, const double *A, const double *B, double L,
+                           int64_t n, int32_t M, double *pts, int32_t *valid, double *params);
+
+/* transform_catenary(point_A, point_B, Catenary(L), theta, gamma) (main_fun.py:38-111):
+ * out[4][n][M][3] = original, theta_rotated, theta_aligned, final; npts[n][2] = number of
+ * meaningful rows in out[0] and out[1..3] (M, or 2 for the straight-segment fallback of
+ * main_fun.py:67-69; remaining rows NaN); z_low[n] = lowest z of `final`
+ * (fully_augmented_catenary.py:21-22). */
+int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B,
+                              const double *theta, const double *gamma, double L,
+                              int64_t n, int32_t M, double *out, int32_t *npts, double *z_low);
+
+/* R @ v per row (velocity_transform_batch.py:100-101): R[n][3][3], v[n][3]. */
+int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, const double *v,
+                              int64_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROVMPC_H */

@@ -1,0 +1,428 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Tolerances: the bar set by BASELINE.json is 1e-5 relative (fp64) on the chosen u and the
+predicted (theta, gamma) trajectory; these tests hold the kernels to 1e-9 (fp64) because
+nothing in the path amplifies rounding at the benchmark's step size, and to the fp32 rule of
+SURVEY section 8(d) (same k* or |J32 - J64| / J64 < 1e-4) for the fp32 variant.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def rv():
+    import rovmpc
+    return rovmpc
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import rovmpc_oracle
+    return rovmpc_oracle
+
+
+def oracle_cfg(orc, cfg):
+    return orc.MPCConfig(N=cfg.N, dt=cfg.dt, v_scale=cfg.v_scale, L=cfg.L, cable_wet_weight=cfg.cable_wet_weight,
+                         c_lo=cfg.c_lo, c_hi=cfg.c_hi, n_shape_pts=cfg.n_shape_pts,
+                         up=1.0 if cfg.frame == "ENU" else -1.0, vt_mode=cfg.vt_mode, prev_mode=cfg.prev_mode,
+                         integrator=cfg.integrator, w_theta=cfg.w_theta, w_gamma=cfg.w_gamma, w_u=cfg.w_u,
+                         w_T=cfg.w_T, w_taut=cfg.w_taut, rho_taut=cfg.rho_taut, w_floor=cfg.w_floor,
+                         z_floor=cfg.z_floor, theta_ref=cfg.theta_ref, gamma_ref=cfg.gamma_ref, U_ref=tuple(cfg.U_ref))
+
+
+def oracle_model(orc, model):
+    return orc.DynamicsModel(model.mean, model.scale, orc.SymbolicModel(model.expr_theta),
+                             orc.SymbolicModel(model.expr_gamma))
+
+
+def rand_rtab(N, seed=7):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(N):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        out.append(q)
+    return np.stack(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# helper mirrors vs golden vectors
+# ---------------------------------------------------------------------------------------------
+
+def test_library_is_the_hip_one(rv):
+    import ctypes
+    lib = rv.load_library()
+    assert b"gfx950" in lib.rovmpc_version()
+    assert os.path.samefile(lib._name, rv.LIB_PATH)
+
+
+def test_predict_every_pareto_row(rv, golden_dir, equations, scaler):
+    g = np.load(os.path.join(golden_dir, "kat_dynamics.npz"))
+    mean, scale = scaler
+    rows_t = equations["dtheta_dt"]["rows"]; rows_g = equations["dgamma_dt"]["rows"]
+    for i in range(max(len(rows_t), len(rows_g))):
+        rt = rows_t[min(i, len(rows_t) - 1)]; rg = rows_g[min(i, len(rows_g) - 1)]
+        m = rv.DynamicsModel(mean, scale, rt["sympy_format"], rg["sympy_format"])
+        with rv.Engine(rv.MPCConfig(N=1, K=1, force_interpreter=True), m) as e:
+            np.testing.assert_allclose(e.predict(g["Xs"], 0), g["out_theta"][min(i, len(rows_t) - 1)], rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(e.predict(g["Xs"], 1), g["out_gamma"][min(i, len(rows_g) - 1)], rtol=1e-12, atol=1e-15)
+
+
+def test_solve_catenary_and_tension(rv, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_solve_catenary.npz"))
+    C = rv.solve_catenary(g["l"], g["dH"], float(g["L"]))
+    assert np.array_equal(np.isnan(C), np.isnan(g["C"]))
+    np.testing.assert_allclose(C, g["C"], rtol=0, atol=1e-11, equal_nan=True)
+    C2, T = rv.cable_tension(g["l"], g["dH"], float(g["L"]), float(g["w_wet"]))
+    np.testing.assert_allclose(T, g["T"], rtol=1e-10)
+    C3 = rv.solve_catenary(g["l_in"], g["dH_in"], 3.0)
+    assert np.array_equal(np.isnan(C3), np.isnan(g["C_in"]))
+    np.testing.assert_allclose(C3, g["C_in"], rtol=0, atol=1e-11, equal_nan=True)
+    # SURVEY KATs incl. both failure modes (taut, root above the bracket)
+    k = rv.solve_catenary([1.0, 1.41421356, 2.0, 2.5, 2.9, 0.5, 3.5], [0, -1, 0.5, -0.3, 0.1, 0, 0], 3.0)
+    np.testing.assert_allclose(k[:5], [5.676892760096155, 3.0791940475045547, 1.5916068034624558,
+                                       0.8396630142778874, 0.309507897379277], rtol=1e-11)
+    assert np.isnan(k[5]) and np.isnan(k[6])
+    assert rv.solve_catenary(np.zeros((0,)), np.zeros((0,)), 3.0).shape == (0,)      # empty input
+    assert rv.solve_catenary(np.full((2, 3), 1.0), 0.0, 3.0).shape == (2, 3)         # broadcasting
+
+
+def test_solve_catenary_large_random_vs_brentq(rv, orc):
+    rng = np.random.default_rng(11)
+    l = rng.uniform(1e-3, 3.5, 4000); dH = rng.uniform(-3.2, 3.2, 4000)
+    ref = orc.solve_catenary_ref(l, dH, 3.0)
+    got = rv.solve_catenary(l, dH, 3.0)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11, equal_nan=True)
+
+
+def test_rodrigues(rv, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_rodrigues.npz"))
+    out = rv.default_engine().rodrigues(g["v"], g["axis"], g["angle"])
+    np.testing.assert_allclose(out, g["out"], rtol=1e-13, atol=1e-15)
+    one = rv.rodrigues_rotation(np.array([1., 1., -1.]), np.array([1., -1., 0.]) / np.sqrt(2), np.radians(-10))
+    np.testing.assert_allclose(one, [0.86201995, 0.86201995, -1.23038336], atol=5e-9)
+    assert one.shape == (3,)
+
+
+def test_transform_catenary_fused_and_generic(rv, orc, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_transform_catenary.npz"))
+    M = int(g["M"])
+    cat = rv.Catenary(float(g["L"]), "ENU", n_points=M)
+    ocat = orc.Catenary(float(g["L"]), "ENU", n_points=M)
+    for i in range(len(g["theta"])):
+        n0, n1 = g["npts"][i]
+        for fn in (cat, ocat):       # fused kernel path / generic-callable path
+            r = rv.transform_catenary(g["A"][i], g["B"][i], fn, g["theta"][i], g["gamma"][i])
+            for out, key, n in zip(r, ("original", "theta_rotated", "theta_aligned", "final"), (n0, n1, n1, n1)):
+                assert out.shape == (n, 3)
+                np.testing.assert_allclose(out, g[key][i][:n], rtol=1e-10, atol=1e-12)
+    out, npts, z = rv.transform_catenary_batch(g["A"], g["B"], g["theta"], g["gamma"], cat)
+    assert np.array_equal(npts, g["npts"])
+    zref = np.array([np.min(g["final"][i][:g["npts"][i][1], 2]) for i in range(len(z))])
+    np.testing.assert_allclose(z, zref, rtol=1e-10, atol=1e-12)
+
+
+def test_catenary_callable_contract(rv, orc):
+    a = np.array([0.1, -0.2, 0.3]); b = np.array([1.2, 0.7, -0.4])
+    for frame in ("ENU", "NED"):
+        got = rv.Catenary(3.0, frame, n_points=24)(a, b)
+        want = orc.Catenary(3.0, frame, n_points=24)(a, b)
+        assert len(got) == 4 and got[3].shape == (24, 3)
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got[:3], want[:3], rtol=1e-10)
+    assert rv.Catenary(3.0)(a, a + np.array([3.0, 0.0, 0.0]))[3] is None       # taut -> None
+    assert rv.Catenary(3.0)(a, a + np.array([0.3, 0.0, 0.0]))[3] is None       # root outside bracket
+    with pytest.raises(ValueError):
+        rv.Catenary(3.0, "XYZ")
+
+
+def test_replay_integrators(rv, golden_dir, equations):
+    from conftest import chosen_row
+    g = np.load(os.path.join(golden_dir, "kat_replay.npz"))
+    th0, ga0 = float(g["theta0"]), float(g["gamma0"])
+    mt = rv.SymbolicRegressor(chosen_row(equations, "dtheta_dt")["sympy_format"])
+    mg = rv.SymbolicRegressor(chosen_row(equations, "dgamma_dt")["sympy_format"])
+    np.testing.assert_allclose(rv.rk4_integration(mt, g["Xs"], g["time"], th0), g["rk4_theta"], rtol=1e-11)
+    np.testing.assert_allclose(rv.rk4_integration(mg, g["Xs"], g["time"], ga0), g["rk4_gamma"], rtol=1e-11)
+    th, ga = rv.integrate_theta_gamma(mt, mg, g["Xs"], g["time"], th0, ga0)
+    np.testing.assert_allclose(np.stack([th, ga]), g["euler"], rtol=1e-11)
+    mt2 = rv.SymbolicRegressor(equations["dtheta_dt"]["rows"][-1]["sympy_format"])
+    mg2 = rv.SymbolicRegressor(equations["dgamma_dt"]["rows"][-1]["sympy_format"])
+    th, ga = rv.rk4_theta_gamma(mt2, mg2, g["Xs"], g["time"], th0, ga0)
+    np.testing.assert_allclose(th, g["rk4_theta_last"], rtol=1e-11)
+    np.testing.assert_allclose(ga, g["rk4_gamma_last"], rtol=1e-11)
+    th, ga = rv.integrate_theta_gamma(mt2, mg2, g["Xs"], g["time"], th0, ga0)
+    np.testing.assert_allclose(np.stack([th, ga]), g["euler_last"], rtol=1e-11)
+    one = rv.rk4_integration(mt, g["Xs"][:1], g["time"][:1], th0)                # T = 1: just y0
+    assert one.shape == (1,) and one[0] == th0
+    np.testing.assert_allclose(mt.predict(g["Xs"]), mt._pair(mt).predict(g["Xs"], 0))
+
+
+def test_velocity_transform(rv):
+    rng = np.random.default_rng(3)
+    R = rand_rtab(50); v = rng.standard_normal((50, 3))
+    np.testing.assert_allclose(rv.velocity_transform(R, v), np.einsum("tij,tj->ti", R, v), rtol=1e-14, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------
+# the hot path vs the oracle
+# ---------------------------------------------------------------------------------------------
+
+def run_both(rv, orc, cfg, model=None, seed=20250523, Rtab=None):
+    model = model or rv.default_model()
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed, cfg.np_dtype)
+    with rv.Engine(cfg, model) as e:
+        if Rtab is not None:
+            e.set_rotation_table(Rtab)
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+        res = e.step(state, U)
+    Jo, trajo, aux = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state),
+                                     U.astype(np.float64), Rtab)
+    return (J, traj, res), (Jo, trajo, aux), (state, U)
+
+
+@pytest.mark.parametrize("vt_mode", [0, 1, 2])
+@pytest.mark.parametrize("prev_mode,integrator", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("force_interp", [False, True])
+def test_rollout_c1_all_modes(rv, orc, vt_mode, prev_mode, integrator, force_interp):
+    """BASELINE config 1 (N=20, K=64) in every mode of the kernel, compiled-in and interpreted."""
+    cfg = rv.MPCConfig(N=20, K=64, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator,
+                       force_interpreter=force_interp)
+    Rtab = rand_rtab(20) if vt_mode == 2 else None
+    (J, traj, res), (Jo, trajo, aux), (state, U) = run_both(rv, orc, cfg, Rtab=Rtab)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    k = int(np.argmin(Jo))
+    assert res.index == k
+    assert np.array_equal(res.u, U[k, 0])
+    assert res.cost == pytest.approx(Jo[k], rel=RTOL)
+    np.testing.assert_allclose(res.traj, trajo[k], rtol=RTOL, atol=1e-13)
+
+
+def test_rollout_c1_scalar_reference_style_oracle(rv, orc):
+    """Same, against the reference-style scalar flavour (per-row predict, scipy brentq, per-point
+    Rodrigues loops) on a few candidates."""
+    cfg = rv.MPCConfig(N=20, K=8)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N)
+    with rv.Engine(cfg) as e:
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+    Jo, trajo, _ = orc.rollout_scalar(oracle_cfg(orc, cfg), oracle_model(orc, rv.default_model()),
+                                      orc.MPCState.from_array(state), U)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+
+
+@pytest.mark.parametrize("ck", [0, 1, 8, 16, 32])
+def test_step_c2_full_size(rv, orc, ck):
+    """BASELINE config 2: N=20, K=4096, fp64 -- chosen u identical, trajectory within 1e-5 (held to 1e-9)."""
+    cfg = rv.MPCConfig(N=20, K=4096, candidates_per_block=ck)
+    (J, traj, res), (Jo, trajo, aux), (state, U) = run_both(rv, orc, cfg)
+    k = int(np.argmin(Jo))
+    assert res.index == k and np.array_equal(res.u, U[k, 0])
+    np.testing.assert_allclose(res.traj, trajo[k], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+
+
+@pytest.mark.parametrize("ct,cg", [(30, 27), (12, 16), (8, 7), (1, 1), (29, 23)])
+def test_rollout_other_pareto_rows(rv, orc, ct, cg):
+    """Interpreter path on other rows of the reference's Pareto fronts (abs, tanh, square, nested sin)."""
+    model = rv.default_model(ct, cg)
+    cfg = rv.MPCConfig(N=12, K=96)
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg, model)
+    np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-8)
+    assert res.index == int(np.argmin(Jo))
+
+
+def test_rollout_c3_fp32(rv, orc):
+    """BASELINE config 3: N=50, K=16384 in fp32, checked against the fp64 oracle with the rule of
+    SURVEY section 8(d): same k*, or |J32 - J64| / J64 < 1e-4 at both minimisers."""
+    cfg = rv.MPCConfig(N=50, K=16384, dtype="f32")
+    (J, traj, res), (Jo, trajo, aux), (state, U) = run_both(rv, orc, cfg)
+    k = int(np.argmin(Jo))
+    ok = res.index == k or (abs(J[k] - Jo[k]) / Jo[k] < 1e-4 and abs(J[res.index] - Jo[res.index]) / Jo[res.index] < 1e-4
+                            and abs(Jo[res.index] - Jo[k]) / Jo[k] < 1e-4)
+    assert ok
+    rel = np.abs(J - Jo) / np.abs(Jo)
+    assert np.median(rel) < 1e-5 and rel.max() < 2e-3
+    terr = np.abs(traj - trajo).max() / np.abs(trajo).max()
+    assert terr < 1e-4
+    # and the same problem in fp64 on the GPU is exact
+    cfg64 = rv.MPCConfig(N=50, K=16384, dtype="f64")
+    with rv.Engine(cfg64) as e:
+        r64 = e.step(state, U.astype(np.float64))
+    assert r64.index == k
+
+
+@pytest.mark.parametrize("K,N,ck", [(1, 1, 0), (67, 7, 16), (130, 3, 64), (5, 50, 4), (1000, 2, 0)])
+def test_ragged_and_tiny_shapes(rv, orc, K, N, ck):
+    cfg = rv.MPCConfig(N=N, K=K, candidates_per_block=ck, n_shape_pts=5)
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    assert res.index == int(np.argmin(Jo))
+
+
+def test_geometry_edge_cases_in_rollout(rv, orc):
+    """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
+    a vertical cable (degenerate xy projection)."""
+    model = rv.default_model()
+    for P1, frame in (((2.6, 1.4, 0.2), "ENU"), ((0.25, 0.1, 0.05), "ENU"), ((0.24, -0.76, 0.3), "NED"),
+                      ((0.0, 0.0, -1.4), "ENU"), ((2.95, 0.0, 0.5), "ENU")):
+        cfg = rv.MPCConfig(N=6, K=40, frame=frame, z_floor=-0.5 if frame == "ENU" else 0.5)
+        state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=5)
+        state[3:6] = P1
+        with rv.Engine(cfg, model) as e:
+            J, traj = e.rollout_costs(state, U, return_traj=True)
+        Jo, trajo, aux = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
+        np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+        np.testing.assert_allclose(J, Jo, rtol=1e-8)
+
+
+def test_nan_costs_never_win_and_ties_take_lowest_index(rv, orc):
+    cfg = rv.MPCConfig(N=5, K=50)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=9)
+    U[3] = np.nan                      # poisoned candidate -> NaN cost -> +inf
+    U[17] = U[31] = U[44] = U[10]      # exact ties
+    U[10] *= 0.0; U[17] *= 0.0; U[31] *= 0.0; U[44] *= 0.0
+    with rv.Engine(cfg) as e:
+        J = e.rollout_costs(state, U)
+        res = e.step(state, U)
+    assert np.isposinf(J[3])
+    assert J[10] == J[17] == J[31] == J[44]
+    Jo, _, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, rv.default_model()), orc.MPCState.from_array(state), U)
+    assert res.index == int(np.argmin(Jo))
+    # force the tie to be the minimum: zero control cost dominates with a huge w_u
+    cfg2 = rv.MPCConfig(N=5, K=50, w_u=1.0)
+    with rv.Engine(cfg2) as e:
+        res2 = e.step(state, U)
+    assert res2.index == 10
+
+
+def test_permutation_and_shard_properties_full_size(rv):
+    """Size-independent properties at K=4096: J is a per-candidate function (permuting candidates
+    permutes J bit-for-bit); the arg-min over shards equals the global arg-min."""
+    cfg = rv.MPCConfig(N=20, K=4096)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=1)
+    perm = np.random.default_rng(0).permutation(cfg.K)
+    with rv.Engine(cfg) as e:
+        J = e.rollout_costs(state, U)
+        Jp = e.rollout_costs(state, U[perm])
+        full = e.step(state, U)
+    assert np.array_equal(Jp, J[perm])
+    assert full.index == int(np.argmin(J)) and full.cost == J.min()
+    with rv.Engine(rv.MPCConfig(N=20, K=1024)) as e4:
+        parts = [e4.step(state, U[i * 1024:(i + 1) * 1024]) for i in range(4)]
+    best = min(range(4), key=lambda i: (parts[i].cost, parts[i].index + i * 1024))
+    assert parts[best].index + best * 1024 == full.index and parts[best].cost == full.cost
+
+
+def test_device_api_and_sharded_select(rv):
+    """Device-pointer entry points with torch tensors; G shards on one GPU + emulated
+    all-reduce(min) + select kernel == un-sharded step; kernels agree with the host statement
+    (pack_record / select_record) used by the gloo tests."""
+    import torch
+    from rovmpc import sharded as sh
+    cfg = rv.MPCConfig(N=20, K=4096)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=2)
+    dev = torch.device("cuda", 0)
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    with rv.Engine(cfg) as e:
+        want = e.step(state, U)
+        d_res = torch.empty(e.result_len, dtype=torch.float64, device=dev)
+        e.step_device(d_state.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        r = d_res.cpu().numpy()
+    assert r[0] == want.cost and int(r[1]) == want.index and np.array_equal(r[2:5], want.u)
+    np.testing.assert_array_equal(r[5:].reshape(-1, 2), want.traj)
+    G = 4
+    Kl = cfg.K // G
+    with rv.Engine(rv.MPCConfig(N=20, K=Kl)) as e:
+        R = e.result_len
+        slots = torch.empty((G, G, R), dtype=torch.int64, device=dev)
+        for g in range(G):
+            dUg = d_U[g * Kl:(g + 1) * Kl].contiguous()
+            e.step_device_sharded(d_state.data_ptr(), dUg.data_ptr(), g * Kl, g, G, slots[g].data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            local = torch.empty(R, dtype=torch.float64, device=dev)
+            e.step_device(d_state.data_ptr(), dUg.data_ptr(), local.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            local[1] += g * Kl
+            assert torch.equal(slots[g], sh.pack_record(local, g, G))            # kernel == host statement
+        reduced = slots.min(dim=0).values.contiguous()                           # what all-reduce(min) leaves
+        out = torch.empty(R, dtype=torch.float64, device=dev)
+        e.select_device(reduced.data_ptr(), G, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, sh.select_record(reduced))
+    o = out.cpu().numpy()
+    assert o[0] == want.cost and int(o[1]) == want.index and np.array_equal(o[2:5], want.u)
+    np.testing.assert_array_equal(o[5:].reshape(-1, 2), want.traj)
+
+
+def test_sharded_mpc_single_rank_nccl(rv):
+    """ShardedMPC end to end on one rank over the real nccl (RCCL) backend."""
+    import torch
+    import torch.distributed as dist
+    from rovmpc.sharded import ShardedMPC
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = rv.MPCConfig(N=20, K=2048)
+        state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=4)
+        dev = torch.device("cuda", 0)
+        with rv.Engine(cfg) as e:
+            want = e.step(state, U)
+            smpc = ShardedMPC(e)
+            d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+            recs = [smpc.step_device(d_state, d_U).clone() for _ in range(3)]
+            smpc.synchronize()
+            for rec in recs:
+                r = rec.cpu().numpy()
+                assert r[0] == want.cost and int(r[1]) == want.index
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mpc_step_surface_and_closed_loop(rv):
+    mpc = rv.MPC(N=20, K=512)
+    state, _ = rv.synthetic_problem(512, 20)
+    u = mpc.step(state)
+    assert u.shape == (3,) and mpc.last.traj.shape == (21, 2) and np.isfinite(mpc.last.cost)
+    u2 = mpc.step(rv.MPCState(P1=state[3:6], V1=state[6:9], theta=-0.03, gamma=-0.05))
+    assert u2.shape == (3,)
+    from rovmpc.closed_loop import run_closed_loop
+    rep = run_closed_loop(mpc.engine, exp_case=12, n_steps=50)
+    assert rep.steps == 50 and rep.u.shape == (50, 3) and np.isfinite(rep.cost).all()
+    assert rep.real_time_factor > 0
+    mpc.close()
+
+
+def test_error_behaviour(rv):
+    with pytest.raises(rv.RovmpcError):
+        rv.Engine(rv.MPCConfig(N=0, K=4))
+    with pytest.raises(rv.RovmpcError):
+        rv.Engine(rv.MPCConfig(N=4, K=4, n_shape_pts=1))
+    with rv.Engine(rv.MPCConfig(N=4, K=8)) as e:
+        state, U = rv.synthetic_problem(8, 4)
+        with pytest.raises(ValueError):
+            e.step(state, U[:4])
+        with pytest.raises(ValueError):
+            e.step(state[:5], U)
+    with rv.Engine(rv.MPCConfig(N=4, K=8, vt_mode=rv.VT_TABLE)) as e:
+        with pytest.raises(rv.RovmpcError):
+            e.step(state, U)                         # rotation table not set
+    with pytest.raises(rv.ExpressionError):
+        rv.DynamicsModel(np.zeros(18), np.ones(18), "x3 + foo(x1)", "x15")
+    with pytest.raises(rv.ExpressionError):
+        rv.DynamicsModel(np.zeros(18), np.ones(18), "x3 + x99", "x15")
