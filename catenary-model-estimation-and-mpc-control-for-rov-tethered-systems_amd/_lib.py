@@ -83,6 +83,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(p):
         raise RovmpcError(-2, f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAME as the system
+    # ROCm).  Two HSA runtimes in one process cannot both own the GPU, so when torch is
+    # present it is imported first and librovmpc binds to the runtime torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -87,43 +87,96 @@ template <typename T> RV_DEV T catenary_f(T C, T l, T L2mH2) {
     return C * C * L2mH2 - T(4) * s * s;
 }
 
-// solve_catenary (main_fun.py:418-431): the root of f on [c_lo, c_hi] that scipy brentq
-// returns, NaN exactly when brentq raises (no sign change: f(c_lo) f(c_hi) > 0).
-// The root is found by Newton on h(u) = sinh(u) - r u  (u = l C / 2, r = sqrt(L^2-dH^2)/l),
-// started at the upper bound u0 of the root given by sinh(u)/u >= 1 + u^2/6 + u^4/120:
-// h is convex and increasing right of its minimum, so the iteration descends monotonically
-// onto the root and converges quadratically (4-6 iterations for the cable geometries of the
-// data set).  *u_out receives l C / 2 so callers can reuse sinh(u) = r u.
-template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) {
-    T L2 = L * L - dH * dH;
-    T flo = catenary_f(c_lo, l, L2);
-    T fhi = catenary_f(c_hi, l, L2);
+// sinh(x)/x - 1 and cosh(x) - 1 for 0 <= x < 0.5 without cancellation (8 series terms,
+// truncation < 1e-19 relative at x = 0.5).
+template <typename T> RV_DEV T sinhc_m1_small(T x2) {
+    return x2 * T(1.0 / 6) * (T(1) + x2 * T(1.0 / 20) * (T(1) + x2 * T(1.0 / 42) * (T(1) + x2 * T(1.0 / 72) *
+           (T(1) + x2 * T(1.0 / 110) * (T(1) + x2 * T(1.0 / 156) * (T(1) + x2 * T(1.0 / 210) * (T(1) + x2 * T(1.0 / 272))))))));
+}
+template <typename T> RV_DEV T cosh_m1_small(T x2) {
+    return x2 * T(0.5) * (T(1) + x2 * T(1.0 / 12) * (T(1) + x2 * T(1.0 / 30) * (T(1) + x2 * T(1.0 / 56) *
+           (T(1) + x2 * T(1.0 / 90) * (T(1) + x2 * T(1.0 / 132) * (T(1) + x2 * T(1.0 / 182) * (T(1) + x2 * T(1.0 / 240))))))));
+}
+
+// sinh(x) for x >= 0: series below 0.5, (e^x - e^-x)/2 above (relative error ~1 ulp either way).
+template <typename T> RV_DEV T sinh_pos(T x) {
+    if (x < T(0.5)) return x * (T(1) + sinhc_m1_small(x * x));
+    const T e = m_exp(x);
+    return T(0.5) * (e - T(1) / e);
+}
+
+// Result of the catenary-parameter solve: C (NaN if none), u = l C / 2 and r = sqrt(L^2-dH^2)/l,
+// so that sinh(u) = r u at the root (reused by the tension rule and the shape samples).
+template <typename T> struct CatRoot { T C, u, r; };
+
+// solve_catenary (main_fun.py:418-431): the root of f(C) = C^2 (L^2 - dH^2) - 4 sinh^2(l C / 2)
+// that scipy brentq returns on [c_lo, c_hi], NaN exactly when brentq raises (no sign change:
+// f(c_lo) f(c_hi) > 0; both bracket values are evaluated with the reference's expression).
+//
+// The root itself comes from Halley's iteration on h(u) = sinh(u) - r u, u = l C / 2:
+//  * start: the root of 1 + u^2/6 + u^4/120 = r (an upper bound, exact to O(u^6)), tightened
+//    by two steps of u <- log(2 r u) when r > 3;
+//  * near-taut cables (u < 0.5) use the cancellation-free forms h = u (S(u) - (r-1)),
+//    h' = (cosh u - 1) - (r - 1) with r - 1 = (L2 - l^2) / (l (sqrt(L2) + l));
+//  * three iterations are unrolled (cubic convergence: enough for every (l, dH) whose root
+//    lies in the default bracket); lanes whose last step was still > 1e-6 relative keep
+//    iterating, so the result never depends on the unroll count.
+template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_lo, T c_hi) {
+    const T L2 = L * L - dH * dH;
+    const T xlo = T(0.5) * l * c_lo, xhi = T(0.5) * l * c_hi;
+    const T slo = sinh_pos(xlo), shi = sinh_pos(xhi);
+    const T flo = c_lo * c_lo * L2 - T(4) * slo * slo;
+    const T fhi = c_hi * c_hi * L2 - T(4) * shi * shi;
     bool ok = !(flo * fhi > T(0)) && m_finite(flo) && m_finite(fhi);
-    T r = m_sqrt(L2) / l;
-    T u = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + (r - T(1)) * T(1.0 / 30.0))), T(0)));
-    if (!(ok && m_finite(u) && u > T(0))) { u = T(1); ok = false; }
-    if (ok) {
-        const T tol = T(2) * m_eps<T>();
-        for (int it = 0; it < 60; ++it) {
-            T sh = m_sinh(u), ch = m_cosh(u);
-            T h = sh - r * u;
-            T un = u - h / (ch - r);
-            if (!(m_finite(un) && un > T(0))) un = u;
-            bool done = m_abs(un - u) <= tol * m_abs(un) || m_abs(h) <= tol * sh;
-            u = un;
-            if (done) break;
-        }
+    const T sq = m_sqrt(L2);
+    T r = sq / l;
+    T rm1 = (L2 - l * l) / (l * (sq + l));
+    T u = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1 * T(1.0 / 30.0))), T(0)));
+    if (!(ok && m_finite(u) && u > T(0))) { ok = false; u = T(1); r = T(2); rm1 = T(1); }
+    if (r > T(3)) {
+        T ul = m_log(T(2) * r * u);
+        ul = m_log(T(2) * r * ul) + T(0.05);
+        if (ul > T(0) && ul < u) u = ul;
     }
-    T C = T(2) * u / l;
-    if (flo == T(0)) C = c_lo;
-    if (fhi == T(0)) C = c_hi;
-    return ok ? C : m_nan<T>();
+    T rel = T(1);
+    auto halley = [&]() {
+        T h, hp, sh;
+        if (u < T(0.5)) {
+            const T u2 = u * u;
+            const T S = sinhc_m1_small(u2);
+            sh = u * (T(1) + S);
+            h = u * (S - rm1);
+            hp = cosh_m1_small(u2) - rm1;
+        } else {
+            const T e = m_exp(u), ei = T(1) / e;
+            sh = T(0.5) * (e - ei);
+            h = sh - r * u;
+            hp = T(0.5) * (e + ei) - r;
+        }
+        T un = u - T(2) * h * hp / (T(2) * hp * hp - h * sh);
+        if (!(m_finite(un) && un > T(0))) un = u;
+        rel = m_abs(un - u) / un;
+        u = un;
+    };
+    halley(); halley(); halley();
+    for (int it = 0; it < 40 && rel > T(1e-6) && ok; ++it) halley();
+    CatRoot<T> out;
+    out.u = u; out.r = r;
+    out.C = T(2) * u / l;
+    if (flo == T(0)) { out.C = c_lo; out.u = xlo; }
+    if (fhi == T(0)) { out.C = c_hi; out.u = xhi; }
+    if (!ok) out.C = m_nan<T>();
+    return out;
+}
+
+template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) {
+    return solve_catenary_root(l, dH, L, c_lo, c_hi).C;
 }
 
 // Tension rule of main_fun.py:302-305: T = (w/L) l / (2 sinh(C l / 2)), NaN -> (w/L) l / 2.
-template <typename T> RV_DEV T cable_tension(T l, T C, T w_per_len) {
-    T Tn = (w_per_len * l) / (T(2) * m_sinh(C * l / T(2)));
-    return (Tn != Tn) ? w_per_len * l / T(2) : Tn;
+// At the root sinh(C l / 2) = sinh(u) = r u, which the solve already holds.
+template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
+    return (c.C == c.C) ? (w_per_len * l) / (T(2) * c.r * c.u) : w_per_len * l / T(2);
 }
 
 // Lowest z (in the "up" sense) of transform_catenary(A, A+rel, Catenary(L), theta, gamma)[3]
@@ -134,6 +187,9 @@ template <typename T> RV_DEV T cable_tension(T l, T C, T w_per_len) {
 // point; only z is needed here, and z_j = m . q_j with m = third row of
 // R_gamma(gamma) R_theta(-theta) = rodrigues(r3, theta_axis, +theta), r3 = third row of
 // R_gamma -- one 3-vector per node instead of two Rodrigues per point.
+// The cosh samples are equally spaced in their argument a + j d, a = atanh(dH'/L) - u',
+// d = 2u'/(M-1), so e^{a+jd} and e^{-(a+jd)} advance by one multiplication each
+// (e^a = sqrt((L+dH')/(L-dH')) e^{-u'}): two exp per node instead of M cosh + atanh.
 template <typename T>
 RV_DEV T augmented_lowest_z(V3<T> rel, T theta, T gamma, T L, int M, T up, T c_lo, T c_hi) {
     V3<T> kt, kg;
@@ -147,21 +203,25 @@ RV_DEV T augmented_lowest_z(V3<T> rel, T theta, T gamma, T L, int M, T up, T c_l
     V3<T> m = rodrigues_unit(r3, kt, st, ct);
     T lp = m_sqrt(Bp.x * Bp.x + Bp.y * Bp.y);
     T dHp = up * Bp.z;
-    T Cp = solve_catenary_C(lp, dHp, L, c_lo, c_hi);
+    CatRoot<T> c = solve_catenary_root(lp, dHp, L, c_lo, c_hi);
     T best;
-    if (Cp == Cp) {
-        T x0 = T(0.5) * lp - m_atanh(dHp / L) / Cp;
-        T ch0 = m_cosh(Cp * x0);
-        T invC = T(1) / Cp;
-        T hx = m.x * Bp.x + m.y * Bp.y;          // horizontal part of m . q_j is t_j * hx
-        T mz = m.z * up;
+    if (c.C == c.C) {
+        const T eu = m_exp(c.u);
+        T E = m_sqrt((L + dHp) / (L - dHp)) / eu;    // e^{a}
+        T Ei = T(1) / E;
+        const T Ed = m_exp(T(2) * c.u / T(M - 1)), Edi = T(1) / Ed;
+        const T ch0 = T(0.5) * (E + Ei);             // cosh(C' x0)
+        const T invC = T(1) / c.C;
+        const T hx = m.x * Bp.x + m.y * Bp.y;        // horizontal part of m . q_j is t_j * hx
+        const T mz = m.z * up * invC;
+        const T invden = T(1) / T(M - 1);
         best = m_inf<T>();
-        T denom = T(M - 1);
         for (int j = 0; j < M; ++j) {
-            T t = T(j) / denom;
-            T s = (m_cosh(Cp * (lp * t - x0)) - ch0) * invC;
-            T z = up * (t * hx + mz * s);
+            const T t = T(j) * invden;
+            const T s = T(0.5) * (E + Ei) - ch0;     // C' s_j
+            const T z = up * (t * hx + mz * s);
             best = (z != z) ? z : (z < best ? z : best);     // np.min propagates NaN
+            E *= Ed; Ei *= Edi;
         }
     } else {
         // catenary_fn(...)[3] is None -> straight segment [A, B'] (main_fun.py:67-69)

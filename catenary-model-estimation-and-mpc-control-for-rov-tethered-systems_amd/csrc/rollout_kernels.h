@@ -324,8 +324,8 @@ rollout_kernel(const RolloutArgs<T> a) {
         const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
         const T dH = a.up * rz;                                              // :293
         const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
-        const T C = solve_catenary_C<T>(l, dH, a.L, a.c_lo, a.c_hi);         // :303
-        const T Tn = cable_tension<T>(l, C, a.w_per_len);                    // :304-305
+        const CatRoot<T> cr = solve_catenary_root<T>(l, dH, a.L, a.c_lo, a.c_hi);   // :303
+        const T Tn = cable_tension<T>(l, cr, a.w_per_len);                   // :304-305
         const T zl = P0z + augmented_lowest_z<T>({rx, ry, rz}, th, ga, a.L, a.M, a.up, a.c_lo, a.c_hi);
         const T eth = th - a.theta_ref, ega = ga - a.gamma_ref;
         const T e0 = u[0] - a.Uref[0], e1 = u[1] - a.Uref[1], e2 = u[2] - a.Uref[2];

@@ -76,10 +76,17 @@ extern "C" const char *rovmpc_last_error(const rovmpc_handle *h) {
 
 extern "C" int32_t rovmpc_result_len(const rovmpc_handle *h) { return h ? 5 + 2 * (h->cfg.N + 1) : 0; }
 
-static int pick_ck(int K, int req) {
-    if (req > 0) return req;
+static size_t lds_need(const rovmpc_config *c, int ck) {
+    // worst case over the model variants this handle may launch
+    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, MODEL_INTERP, c->vt_mode) * sizeof(double)
+                                  : rollout_lds_elems<float>(c->N, ck, MODEL_INTERP, c->vt_mode) * sizeof(float);
+}
+
+static int pick_ck(const rovmpc_config *c) {
+    if (c->candidates_per_block > 0) return c->candidates_per_block;
     int ck = 1;
-    while (ck < 16 && K / (ck * 2) >= 1024) ck *= 2;     // aim at ~4 resident workgroups per CU
+    while (ck < 16 && c->K / (ck * 2) >= 1024) ck *= 2;     // aim at ~4 resident workgroups per CU
+    while (ck > 1 && lds_need(c, ck) > 40 * 1024) ck /= 2;   // and keep 4 of them inside 160 KiB of LDS
     return ck;
 }
 
@@ -117,14 +124,13 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *h = new rovmpc_handle();
     h->cfg = *cfg;
     h->esz = cfg->dtype == ROVMPC_F64 ? 8 : 4;
-    h->CK = pick_ck(cfg->K, cfg->candidates_per_block);
+    h->CK = pick_ck(cfg);
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     int items = (cfg->N + 1) * h->CK;
     h->NT = items >= 256 ? 256 : ((items + 63) / 64) * 64;
     if (h->NT < 64) h->NT = 64;
     // worst-case LDS over the model/vt variants this handle may launch
-    size_t need = cfg->dtype == ROVMPC_F64 ? lds_bytes_for<double>(h, MODEL_INTERP, cfg->vt_mode)
-                                           : lds_bytes_for<float>(h, MODEL_INTERP, cfg->vt_mode);
+    size_t need = lds_need(cfg, h->CK);
     if (need > 160 * 1024) {
         g_create_error = "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
         delete h;

@@ -69,9 +69,9 @@ solve_catenary_kernel(const double *l, const double *dH, double L, double c_lo, 
                       double w_per_len, long long n, double *C_out, double *T_out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double C = solve_catenary_C<double>(l[i], dH[i], L, c_lo, c_hi);
-    C_out[i] = C;
-    if (T_out) T_out[i] = cable_tension<double>(l[i], C, w_per_len);
+    const CatRoot<double> c = solve_catenary_root<double>(l[i], dH[i], L, c_lo, c_hi);
+    C_out[i] = c.C;
+    if (T_out) T_out[i] = cable_tension<double>(l[i], c, w_per_len);
 }
 
 // main_fun.py:18-35 with the axis normalisation of :30.

@@ -220,7 +220,7 @@ def test_rollout_c1_scalar_reference_style_oracle(rv, orc):
     np.testing.assert_allclose(J, Jo, rtol=RTOL)
 
 
-@pytest.mark.parametrize("ck", [0, 1, 8, 16, 32])
+@pytest.mark.parametrize("ck", [0, 1, 2, 8, 16])
 def test_step_c2_full_size(rv, orc, ck):
     """BASELINE config 2: N=20, K=4096, fp64 -- chosen u identical, trajectory within 1e-5 (held to 1e-9)."""
     cfg = rv.MPCConfig(N=20, K=4096, candidates_per_block=ck)
@@ -385,8 +385,11 @@ def test_sharded_mpc_single_rank_nccl(rv):
             want = e.step(state, U)
             smpc = ShardedMPC(e)
             d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
-            recs = [smpc.step_device(d_state, d_U).clone() for _ in range(3)]
-            smpc.synchronize()
+            recs = []
+            for _ in range(3):
+                rec = smpc.step_device(d_state, d_U)       # valid after synchronize() (side stream)
+                smpc.synchronize()
+                recs.append(rec.clone())
             for rec in recs:
                 r = rec.cpu().numpy()
                 assert r[0] == want.cost and int(r[1]) == want.index
