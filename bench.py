@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
+    ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
-                           candidates_per_block=args.ck, force_interpreter=args.interp)
+                           candidates_per_block=args.ck, force_interpreter=args.interp, debug_flags=args.debug_flags)
     eng = rovmpc.Engine(cfg)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     pools = []

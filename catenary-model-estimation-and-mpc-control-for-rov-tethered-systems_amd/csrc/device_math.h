@@ -11,11 +11,74 @@ namespace rovmpc {
 
 #define RV_DEV __device__ __forceinline__
 
-RV_DEV double m_sin(double x) { return ::sin(x); }
+// fp64 sin/cos.  The device library's double-precision sin/cos carry their argument
+// reduction and polynomial in double-double arithmetic (~120 VALU instructions per call, a
+// Payne-Hanek branch on top); the rollout's sequential phase issues up to ten of them per
+// horizon step, which made it the kernel's critical path.  For |x| < 2^26 the two-FMA
+// Cody-Waite reduction r = x - k (pi/2)_hi - k (pi/2)_lo is exact to < 1 ulp of r and the
+// fdlibm minimax kernels (k_sin.c / k_cos.c, degree 13 / 14) give sin and cos of r to < 1 ulp:
+// ~35 instructions for the pair.  Larger arguments take the library path (a branch no rollout
+// on physical data ever enters).
+// Out-of-line so the six call sites of the sequential phase do not each inline ~150
+// instructions of Payne-Hanek reduction they never execute.
+__device__ __attribute__((noinline)) double2 slow_sincos_f64(double x) { double s, c; ::sincos(x, &s, &c); return make_double2(s, c); }
+
+// The 15 fp64 literals of the fast path.  gfx950 VALU instructions cannot carry a 64-bit
+// literal, so each use of a coefficient costs two s_mov_b32 (or, kept live across a loop, SGPR
+// pairs that spill to VGPR lanes).  pin() launders them into VGPRs once per kernel phase.
+struct TrigK {
+    double inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, S4, S5, S6, C1, C2, C3, C4, C5, C6;
+};
+RV_DEV double pin_vgpr(double v) { asm volatile("" : "+v"(v)); return v; }
+RV_DEV TrigK trig_constants(bool pin) {
+    TrigK k = {6.36619772367581382433e-01, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+               -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+               2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+               4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+               -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11};
+    if (pin) {
+        double *p = &k.inv_pio2;
+        #pragma unroll
+        for (int i = 0; i < 15; ++i) p[i] = pin_vgpr(p[i]);
+    }
+    return k;
+}
+
+RV_DEV void fast_sincos_k(double x, const TrigK &K, double *s, double *c) {
+    if (!(::fabs(x) < 67108864.0)) { const double2 r = slow_sincos_f64(x); *s = r.x; *c = r.y; return; }
+    const double k = ::rint(x * K.inv_pio2);
+    double r = ::fma(-k, K.pio2_hi, x);
+    r = ::fma(-k, K.pio2_lo, r);
+    const double z = r * r;
+    const double ps = K.S1 + z * (K.S2 + z * (K.S3 + z * (K.S4 + z * (K.S5 + z * K.S6))));
+    const double sr = ::fma(z * r, ps, r);
+    const double pc = K.C1 + z * (K.C2 + z * (K.C3 + z * (K.C4 + z * (K.C5 + z * K.C6))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+    const int q = (int)k;
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+RV_DEV void fast_sincos_f64(double x, double *s, double *c) { fast_sincos_k(x, trig_constants(false), s, c); }
+// Trig context: fp64 carries the pinned constants, fp32 uses the device library directly.
+template <typename T> struct Trig;
+template <> struct Trig<double> {
+    TrigK K;
+    RV_DEV explicit Trig(bool pin) : K(trig_constants(pin)) {}
+    RV_DEV double sin(double x) const { double s, c; fast_sincos_k(x, K, &s, &c); return s; }
+    RV_DEV void sincos(double x, double *s, double *c) const { fast_sincos_k(x, K, s, c); }
+};
+template <> struct Trig<float> {
+    RV_DEV explicit Trig(bool) {}
+    RV_DEV float sin(float x) const { return ::sinf(x); }
+    RV_DEV void sincos(float x, float *s, float *c) const { ::sincosf(x, s, c); }
+};
+RV_DEV double m_sin(double x) { double s, c; fast_sincos_f64(x, &s, &c); return s; }
 RV_DEV float  m_sin(float x)  { return ::sinf(x); }
-RV_DEV double m_cos(double x) { return ::cos(x); }
+RV_DEV double m_cos(double x) { double s, c; fast_sincos_f64(x, &s, &c); return c; }
 RV_DEV float  m_cos(float x)  { return ::cosf(x); }
-RV_DEV void m_sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+RV_DEV void m_sincos(double x, double *s, double *c) { fast_sincos_f64(x, s, c); }
 RV_DEV void m_sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
 RV_DEV double m_sinh(double x) { return ::sinh(x); }
 RV_DEV float  m_sinh(float x)  { return ::sinhf(x); }
@@ -109,64 +172,87 @@ template <typename T> RV_DEV T sinh_pos(T x) {
 // so that sinh(u) = r u at the root (reused by the tension rule and the shape samples).
 template <typename T> struct CatRoot { T C, u, r; };
 
-// solve_catenary (main_fun.py:418-431): the root of f(C) = C^2 (L^2 - dH^2) - 4 sinh^2(l C / 2)
-// that scipy brentq returns on [c_lo, c_hi], NaN exactly when brentq raises (no sign change:
-// f(c_lo) f(c_hi) > 0; both bracket values are evaluated with the reference's expression).
+// solve_catenary (main_fun.py:418-431): the root C* of f(C) = C^2 (L^2 - dH^2) - 4 sinh^2(l C / 2)
+// that scipy brentq returns on [c_lo, c_hi], NaN when brentq raises.  brentq raises exactly
+// when f(c_lo) f(c_hi) > 0; f is positive below its single positive root and negative above
+// (and negative everywhere for a taut cable, L^2 - dH^2 <= l^2), so that is the same as
+// "no root, or the root outside [c_lo, c_hi]" -- decided here from the root itself instead of
+// two more sinh evaluations (the two statements differ only when the root is within an ulp of
+// a bracket end).
 //
-// The root itself comes from Halley's iteration on h(u) = sinh(u) - r u, u = l C / 2:
+// The root comes from Halley's iteration on h(u) = sinh(u) - r u, u = l C / 2,
+// r = sqrt(L^2 - dH^2) / l:
 //  * start: the root of 1 + u^2/6 + u^4/120 = r (an upper bound, exact to O(u^6)), tightened
-//    by two steps of u <- log(2 r u) when r > 3;
+//    by two steps of u <- log(2 r u) when r > 8;
 //  * near-taut cables (u < 0.5) use the cancellation-free forms h = u (S(u) - (r-1)),
 //    h' = (cosh u - 1) - (r - 1) with r - 1 = (L2 - l^2) / (l (sqrt(L2) + l));
-//  * three iterations are unrolled (cubic convergence: enough for every (l, dH) whose root
-//    lies in the default bracket); lanes whose last step was still > 1e-6 relative keep
-//    iterating, so the result never depends on the unroll count.
-template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_lo, T c_hi) {
-    const T L2 = L * L - dH * dH;
-    const T xlo = T(0.5) * l * c_lo, xhi = T(0.5) * l * c_hi;
-    const T slo = sinh_pos(xlo), shi = sinh_pos(xhi);
-    const T flo = c_lo * c_lo * L2 - T(4) * slo * slo;
-    const T fhi = c_hi * c_hi * L2 - T(4) * shi * shi;
-    bool ok = !(flo * fhi > T(0)) && m_finite(flo) && m_finite(fhi);
-    const T sq = m_sqrt(L2);
-    T r = sq / l;
-    T rm1 = (L2 - l * l) / (l * (sq + l));
-    T u = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1 * T(1.0 / 30.0))), T(0)));
-    if (!(ok && m_finite(u) && u > T(0))) { ok = false; u = T(1); r = T(2); rm1 = T(1); }
-    if (r > T(3)) {
-        T ul = m_log(T(2) * r * u);
-        ul = m_log(T(2) * r * ul) + T(0.05);
-        if (ul > T(0) && ul < u) u = ul;
-    }
-    T rel = T(1);
-    auto halley = [&]() {
-        T h, hp, sh;
-        if (u < T(0.5)) {
-            const T u2 = u * u;
-            const T S = sinhc_m1_small(u2);
-            sh = u * (T(1) + S);
-            h = u * (S - rm1);
-            hp = cosh_m1_small(u2) - rm1;
-        } else {
-            const T e = m_exp(u), ei = T(1) / e;
-            sh = T(0.5) * (e - ei);
-            h = sh - r * u;
-            hp = T(0.5) * (e + ei) - r;
+//  * three iterations are unrolled (cubic convergence: the last step is < 2e-8 relative for
+//    every r <= 8); systems whose last step was still > 1e-6 keep iterating, so the result
+//    never depends on the unroll count.
+// NS independent systems advance in lockstep: the per-node rollout needs two solves (cable
+// tension on the straight geometry, shape on the theta-rotated end point) and interleaving
+// them doubles the instruction-level parallelism of an otherwise latency-bound chain.
+template <typename T, int NS>
+RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_lo, T c_hi, CatRoot<T> (&out)[NS]) {
+    T u[NS], r[NS], rm1[NS], rel[NS];
+    bool ok[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const T L2 = L * L - dH[s] * dH[s];
+        const T sq = m_sqrt(L2);
+        r[s] = sq / l[s];
+        rm1[s] = (L2 - l[s] * l[s]) / (l[s] * (sq + l[s]));
+        u[s] = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1[s] * T(1.0 / 30.0))), T(0)));
+        ok[s] = rm1[s] > T(0) && m_finite(r[s]) && m_finite(u[s]) && u[s] > T(0);
+        if (!ok[s]) { u[s] = T(1); r[s] = T(2); rm1[s] = T(1); }
+        if (r[s] > T(8)) {
+            T ul = m_log(T(2) * r[s] * u[s]);
+            ul = m_log(T(2) * r[s] * ul) + T(0.05);
+            if (ul > T(0) && ul < u[s]) u[s] = ul;
         }
-        T un = u - T(2) * h * hp / (T(2) * hp * hp - h * sh);
-        if (!(m_finite(un) && un > T(0))) un = u;
-        rel = m_abs(un - u) / un;
-        u = un;
+        rel[s] = T(1);
+    }
+    auto halley = [&](int s) {
+        T h, hp, sh;
+        if (u[s] < T(0.5)) {
+            const T u2 = u[s] * u[s];
+            const T S = sinhc_m1_small(u2);
+            sh = u[s] * (T(1) + S);
+            h = u[s] * (S - rm1[s]);
+            hp = cosh_m1_small(u2) - rm1[s];
+        } else {
+            const T e = m_exp(u[s]), ei = T(1) / e;
+            sh = T(0.5) * (e - ei);
+            h = sh - r[s] * u[s];
+            hp = T(0.5) * (e + ei) - r[s];
+        }
+        T un = u[s] - T(2) * h * hp / (T(2) * hp * hp - h * sh);
+        if (!(m_finite(un) && un > T(0))) un = u[s];
+        rel[s] = m_abs(un - u[s]) / un;
+        u[s] = un;
     };
-    halley(); halley(); halley();
-    for (int it = 0; it < 40 && rel > T(1e-6) && ok; ++it) halley();
-    CatRoot<T> out;
-    out.u = u; out.r = r;
-    out.C = T(2) * u / l;
-    if (flo == T(0)) { out.C = c_lo; out.u = xlo; }
-    if (fhi == T(0)) { out.C = c_hi; out.u = xhi; }
-    if (!ok) out.C = m_nan<T>();
-    return out;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) halley(s);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        for (int it = 0; it < 40 && rel[s] > T(1e-6) && ok[s]; ++it) halley(s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const T C = T(2) * u[s] / l[s];
+        const bool in = ok[s] && C >= c_lo && C <= c_hi;
+        out[s].u = u[s]; out[s].r = r[s];
+        out[s].C = in ? C : m_nan<T>();
+    }
+}
+
+template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_lo, T c_hi) {
+    const T la[1] = {l}, da[1] = {dH};
+    CatRoot<T> o[1];
+    solve_catenary_roots<T, 1>(la, da, L, c_lo, c_hi, o);
+    return o[0];
 }
 
 template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) {
@@ -180,52 +266,59 @@ template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
 }
 
 // Lowest z (in the "up" sense) of transform_catenary(A, A+rel, Catenary(L), theta, gamma)[3]
-// (main_fun.py:38-111 + fully_augmented_catenary.py:21-22), returned relative to A.z.
+// (main_fun.py:38-111 + fully_augmented_catenary.py:21-22), relative to A.z, in two halves
+// around the catenary solve of the theta-rotated end point B'.
 // The M samples of the theta-rotated catenary are q_j = (t_j B'x, t_j B'y, up*s_j) relative
 // to A with s_j = (cosh(C'(l' t_j - x0)) - cosh(C' x0))/C'; the reference then applies
 // Rodrigues(-theta) about the theta axis and Rodrigues(+gamma) about the gamma axis to every
 // point; only z is needed here, and z_j = m . q_j with m = third row of
 // R_gamma(gamma) R_theta(-theta) = rodrigues(r3, theta_axis, +theta), r3 = third row of
 // R_gamma -- one 3-vector per node instead of two Rodrigues per point.
+template <typename T> struct AugShape { V3<T> Bp, m; T lp, dHp; };
+
+template <typename T, typename TrigT>
+RV_DEV AugShape<T> augmented_prepare(V3<T> rel, T theta, T gamma, T up, const TrigT &trig) {
+    V3<T> kt, kg;
+    theta_gamma_axes(rel, kt, kg);
+    T st, ct, sg, cg;
+    trig.sincos(theta, &st, &ct);
+    trig.sincos(gamma, &sg, &cg);
+    AugShape<T> a;
+    a.Bp = rodrigues_unit(rel, kt, st, ct);                          // main_fun.py:92
+    const T omc = T(1) - cg;
+    const V3<T> r3 = {-kg.y * sg + omc * kg.z * kg.x, kg.x * sg + omc * kg.z * kg.y, cg + omc * kg.z * kg.z};
+    a.m = rodrigues_unit(r3, kt, st, ct);
+    a.lp = m_sqrt(a.Bp.x * a.Bp.x + a.Bp.y * a.Bp.y);
+    a.dHp = up * a.Bp.z;
+    return a;
+}
+
 // The cosh samples are equally spaced in their argument a + j d, a = atanh(dH'/L) - u',
 // d = 2u'/(M-1), so e^{a+jd} and e^{-(a+jd)} advance by one multiplication each
 // (e^a = sqrt((L+dH')/(L-dH')) e^{-u'}): two exp per node instead of M cosh + atanh.
 template <typename T>
-RV_DEV T augmented_lowest_z(V3<T> rel, T theta, T gamma, T L, int M, T up, T c_lo, T c_hi) {
-    V3<T> kt, kg;
-    theta_gamma_axes(rel, kt, kg);
-    T st, ct, sg, cg;
-    m_sincos(theta, &st, &ct);
-    m_sincos(gamma, &sg, &cg);
-    V3<T> Bp = rodrigues_unit(rel, kt, st, ct);                     // main_fun.py:92
-    T omc = T(1) - cg;
-    V3<T> r3 = {-kg.y * sg + omc * kg.z * kg.x, kg.x * sg + omc * kg.z * kg.y, cg + omc * kg.z * kg.z};
-    V3<T> m = rodrigues_unit(r3, kt, st, ct);
-    T lp = m_sqrt(Bp.x * Bp.x + Bp.y * Bp.y);
-    T dHp = up * Bp.z;
-    CatRoot<T> c = solve_catenary_root(lp, dHp, L, c_lo, c_hi);
+RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) {
     T best;
     if (c.C == c.C) {
         const T eu = m_exp(c.u);
-        T E = m_sqrt((L + dHp) / (L - dHp)) / eu;    // e^{a}
+        T E = m_sqrt((L + a.dHp) / (L - a.dHp)) / eu;    // e^{a}
         T Ei = T(1) / E;
-        const T Ed = m_exp(T(2) * c.u / T(M - 1)), Edi = T(1) / Ed;
-        const T ch0 = T(0.5) * (E + Ei);             // cosh(C' x0)
-        const T invC = T(1) / c.C;
-        const T hx = m.x * Bp.x + m.y * Bp.y;        // horizontal part of m . q_j is t_j * hx
-        const T mz = m.z * up * invC;
         const T invden = T(1) / T(M - 1);
+        const T Ed = m_exp(T(2) * c.u * invden), Edi = T(1) / Ed;
+        const T ch0 = T(0.5) * (E + Ei);                 // cosh(C' x0)
+        const T hx = a.m.x * a.Bp.x + a.m.y * a.Bp.y;    // horizontal part of m . q_j is t_j * hx
+        const T mz = a.m.z * up / c.C;
         best = m_inf<T>();
         for (int j = 0; j < M; ++j) {
             const T t = T(j) * invden;
-            const T s = T(0.5) * (E + Ei) - ch0;     // C' s_j
+            const T s = T(0.5) * (E + Ei) - ch0;         // C' s_j
             const T z = up * (t * hx + mz * s);
-            best = (z != z) ? z : (z < best ? z : best);     // np.min propagates NaN
+            best = (z != z) ? z : (z < best ? z : best); // np.min propagates NaN
             E *= Ed; Ei *= Edi;
         }
     } else {
         // catenary_fn(...)[3] is None -> straight segment [A, B'] (main_fun.py:67-69)
-        T zb = up * dot3(m, Bp);
+        const T zb = up * dot3(a.m, a.Bp);
         best = (zb != zb) ? zb : (zb < T(0) ? zb : T(0));
     }
     return up * best;

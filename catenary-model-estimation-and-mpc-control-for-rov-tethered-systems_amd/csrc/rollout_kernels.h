@@ -40,11 +40,11 @@ template <typename T> struct RolloutArgs {
     double *blk_cost;         // [nblocks]
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
-    int N, K, CK, M, n_th, n_ga, prev_mode, integrator;
+    int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug;
     T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up;
     T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
     T Uref[3];
-    T mean[18], inv_scale[18];
+    const T *msc;             // device: mean[18] then 1/scale[18]
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -101,9 +101,20 @@ RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restric
 // LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
 #define RV_PL(base, p, n, c) (base)[((p) * (N + 1) + (n)) * CK + (c)]
 
+// Node planes kept in LDS.  The compiled-in model reads only x3 (and x14..x17, which are
+// state), so its workgroups keep P (3), theta/gamma (2) and either the x3 plane or the five
+// rotation-axis components; the interpreter keeps the whole scaled exogenous row.
+__host__ __device__ inline int rollout_nx(int model, int vt) {
+    return model == MODEL_BUILTIN ? (vt == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
+}
+__host__ __device__ inline int rollout_na(int model, int vt) {
+    return vt == ROVMPC_VT_COMPOSE ? (model == MODEL_BUILTIN ? 5 : NAX) : 0;
+}
+constexpr int HDR = 40;            // header: block-best lane + mean[18] + inv_scale[18]
+
 template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt) {
-    size_t planes = 3 /*P*/ + NEXO + 2 /*theta,gamma*/ + (vt == ROVMPC_VT_COMPOSE ? NAX : 0);
-    size_t e = 4;                                    // header (block-best lane)
+    size_t planes = 3 /*P*/ + 2 /*theta,gamma*/ + rollout_nx(model, vt) + rollout_na(model, vt);
+    size_t e = HDR;
     e += planes * (size_t)(N + 1) * CK;              // node planes
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
     e += (size_t)CK * N;                             // node costs
@@ -112,7 +123,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 }
 
 template <typename T, int MODEL, int VT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 rollout_kernel(const RolloutArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -120,15 +131,18 @@ rollout_kernel(const RolloutArgs<T> a) {
     const int tid = threadIdx.x, NT = blockDim.x;
     const int k0 = blockIdx.x * CK;
     const int nvalid = min(CK, K - k0);
+    constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
+    constexpr int NA = VT == ROVMPC_VT_COMPOSE ? (MODEL == MODEL_BUILTIN ? 5 : NAX) : 0;
 
     // carve LDS
     int *s_best_c = reinterpret_cast<int *>(smem);   // header
+    T *sMean = smem + 2, *sInv = smem + 20;          // scaler constants (lane-uniform reads)
     const int US = (3 * N) | 1;                      // padded U row stride
-    T *sP = smem + 4;                                // 3 planes
-    T *sX = sP + 3 * (N + 1) * CK;                   // NEXO planes (scaled features)
-    T *sY = sX + NEXO * (N + 1) * CK;                // theta, gamma planes
-    T *sA = sY + 2 * (N + 1) * CK;                   // NAX planes (COMPOSE only)
-    T *sU = sA + (VT == ROVMPC_VT_COMPOSE ? NAX * (N + 1) * CK : 0);   // [c][n][3]
+    T *sP = smem + HDR;                              // 3 planes
+    T *sY = sP + 3 * (N + 1) * CK;                   // theta, gamma planes
+    T *sX = sY + 2 * (N + 1) * CK;                   // NX planes (scaled features)
+    T *sA = sX + NX * (N + 1) * CK;                  // NA planes (rotation axes [, unit_rel])
+    T *sU = sA + NA * (N + 1) * CK;                  // [c][n][3]
     T *sC = sU + CK * US;                            // [n][c] node costs
     T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
 
@@ -140,6 +154,7 @@ rollout_kernel(const RolloutArgs<T> a) {
             const int c = i / (3 * N), j = i - c * (3 * N);
             sU[c * US + j] = (i < tot) ? src[i] : T(0);
         }
+        if (tid < 18) { sMean[tid] = a.msc[tid]; sInv[tid] = a.msc[18 + tid]; }
     }
     // state (uniform loads)
     const double *sd = a.state;
@@ -162,160 +177,237 @@ rollout_kernel(const RolloutArgs<T> a) {
     __syncthreads();
 
     // ---- phase 2: exogenous feature rows of every node ------------------------------------
-    for (int i = tid; i < (N + 1) * CK; i += NT) {
+    // V_n (feature-frame velocity at node n) when it does not depend on (theta, gamma)
+    auto vel = [&](int c, int node, T &vx, T &vy, T &vz) {
+        if (node == 0) { vx = V0x; vy = V0y; vz = V0z; return; }
+        const T *u = &sU[c * US + (node - 1) * 3];
+        if (VT == ROVMPC_VT_TABLE) {
+            const T *R = a.Rtab + (node - 1) * 9;                            // R @ v
+            vx = R[0] * u[0] + R[1] * u[1] + R[2] * u[2];
+            vy = R[3] * u[0] + R[4] * u[1] + R[5] * u[2];
+            vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
+        } else { vx = u[0]; vy = u[1]; vz = u[2]; }
+    };
+    for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
         const int n = i / CK, c = i % CK;
         const T Px = RV_PL(sP, 0, n, c), Py = RV_PL(sP, 1, n, c), Pz = RV_PL(sP, 2, n, c);
         const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
-        const T nr = m_sqrt(rx * rx + ry * ry + rz * rz);
-        const T inr = T(1) / (nr + T(1e-8));                                 // :26
-        const T ux = rx * inr, uy = ry * inr, uz = rz * inr;
-        const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
-        RV_PL(sX, 0, n, c) = (Px - a.mean[0]) * a.inv_scale[0];
-        RV_PL(sX, 1, n, c) = (Py - a.mean[1]) * a.inv_scale[1];
-        RV_PL(sX, 2, n, c) = (Pz - a.mean[2]) * a.inv_scale[2];
-        RV_PL(sX, 9, n, c) = (ux - a.mean[9]) * a.inv_scale[9];
-        RV_PL(sX, 10, n, c) = (uy - a.mean[10]) * a.inv_scale[10];
-        RV_PL(sX, 11, n, c) = (uz - a.mean[11]) * a.inv_scale[11];
-        RV_PL(sX, 12, n, c) = (tension - a.mean[12]) * a.inv_scale[12];
         if (VT == ROVMPC_VT_COMPOSE) {
             V3<T> kt, kg;
             theta_gamma_axes<T>({rx, ry, rz}, kt, kg);
             RV_PL(sA, 0, n, c) = kt.x; RV_PL(sA, 1, n, c) = kt.y;
             RV_PL(sA, 2, n, c) = kg.x; RV_PL(sA, 3, n, c) = kg.y; RV_PL(sA, 4, n, c) = kg.z;
+        }
+        if (MODEL == MODEL_BUILTIN) {
+            if (VT != ROVMPC_VT_COMPOSE) {
+                T Vx, Vy, Vz;
+                vel(c, n, Vx, Vy, Vz);
+                RV_PL(sX, 0, n, c) = (Vx - sMean[3]) * sInv[3];              // x3 is all the model reads
+            }
+            continue;
+        }
+        const T nr = m_sqrt(rx * rx + ry * ry + rz * rz);
+        const T inr = T(1) / (nr + T(1e-8));                                 // :26
+        const T ux = rx * inr, uy = ry * inr, uz = rz * inr;
+        const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
+        RV_PL(sX, 0, n, c) = (Px - sMean[0]) * sInv[0];
+        RV_PL(sX, 1, n, c) = (Py - sMean[1]) * sInv[1];
+        RV_PL(sX, 2, n, c) = (Pz - sMean[2]) * sInv[2];
+        RV_PL(sX, 9, n, c) = (ux - sMean[9]) * sInv[9];
+        RV_PL(sX, 10, n, c) = (uy - sMean[10]) * sInv[10];
+        RV_PL(sX, 11, n, c) = (uz - sMean[11]) * sInv[11];
+        RV_PL(sX, 12, n, c) = (tension - sMean[12]) * sInv[12];
+        if (VT == ROVMPC_VT_COMPOSE) {
             RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
         } else {
             // velocity features do not depend on (theta, gamma): finish the row here
             T Vx, Vy, Vz, Wx, Wy, Wz;           // V_n and V_{n-1}
-            auto vel = [&](int node, T &vx, T &vy, T &vz) {
-                if (node == 0) { vx = V0x; vy = V0y; vz = V0z; return; }
-                const T *u = &sU[c * US + (node - 1) * 3];
-                if (VT == ROVMPC_VT_TABLE) {
-                    const T *R = a.Rtab + (node - 1) * 9;                    // R @ v
-                    vx = R[0] * u[0] + R[1] * u[1] + R[2] * u[2];
-                    vy = R[3] * u[0] + R[4] * u[1] + R[5] * u[2];
-                    vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
-                } else { vx = u[0]; vy = u[1]; vz = u[2]; }
-            };
-            vel(n, Vx, Vy, Vz);
+            vel(c, n, Vx, Vy, Vz);
             T Ax, Ay, Az;
             if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
-            else { vel(n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * a.inv_h; Ay = (Vy - Wy) * a.inv_h; Az = (Vz - Wz) * a.inv_h; }
+            else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * a.inv_h; Ay = (Vy - Wy) * a.inv_h; Az = (Vz - Wz) * a.inv_h; }
             const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
             const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));   // :31
-            RV_PL(sX, 3, n, c) = (Vx - a.mean[3]) * a.inv_scale[3];
-            RV_PL(sX, 4, n, c) = (Vy - a.mean[4]) * a.inv_scale[4];
-            RV_PL(sX, 5, n, c) = (Vz - a.mean[5]) * a.inv_scale[5];
-            RV_PL(sX, 6, n, c) = (Ax - a.mean[6]) * a.inv_scale[6];
-            RV_PL(sX, 7, n, c) = (Ay - a.mean[7]) * a.inv_scale[7];
-            RV_PL(sX, 8, n, c) = (Az - a.mean[8]) * a.inv_scale[8];
-            RV_PL(sX, 13, n, c) = (ap - a.mean[13]) * a.inv_scale[13];
+            RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
+            RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
+            RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
+            RV_PL(sX, 6, n, c) = (Ax - sMean[6]) * sInv[6];
+            RV_PL(sX, 7, n, c) = (Ay - sMean[7]) * sInv[7];
+            RV_PL(sX, 8, n, c) = (Az - sMean[8]) * sInv[8];
+            RV_PL(sX, 13, n, c) = (ap - sMean[13]) * sInv[13];
         }
     }
     __syncthreads();
 
     // ---- phase 3: closed-loop integration of (theta, gamma) -------------------------------
-    if (tid < CK) {
+    if (MODEL == MODEL_BUILTIN) {
+        // saved_models/equations_dtheta_dt.csv complexity 13:
+        //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
+        // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
+        // Of the 18 slots only x3, x15, x16, x17 are read, and every sine argument of a step is
+        // known once (theta_n, gamma_n) are.  The phase is sequential in n and issue-bound on
+        // fp64 trig, so each candidate gets FOUR lanes (c + 16 j, j = role): the four
+        // trigonometric evaluations that open a step -- sincos(theta_n), sincos(gamma_n),
+        // sin(x17 at t_n+1), sin(x17 at the midpoint) -- run as ONE sincos over the wave, the two
+        // that close it -- sin(x3 at t_n+1), sin(x3 at the midpoint) -- as one more; results
+        // move between a candidate's lanes with ds_bpermute.  All four lanes carry the
+        // (cheap) state update redundantly, so no other exchange is needed.
+        const int nwaves3 = (CK + 15) / 16;
+        if (tid < nwaves3 * 64) {
+            const int lane = tid & 63, c16 = lane & 15, role = lane >> 4;
+            const int cc = (tid >> 6) * 16 + c16;               // candidate of this lane
+            const bool live = cc < CK;
+            const int c = live ? cc : CK - 1;                   // clamp reads of padding lanes
+            const int nsteps = (a.debug & 1) ? 0 : N;
+            const Trig<T> trig(true);
+            const T m3 = sMean[3], i3 = sInv[3], m15 = sMean[15], i15 = sInv[15];
+            const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
+            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+            const bool euler = a.integrator == ROVMPC_EULER;
+            const T hh = T(0.5) * a.h, h6 = a.h / T(6);
+            const T KT = T(0.048152514);
+            T th = th0, ga = ga0, thm = thm0, gam = gam0;
+            if (live && role == 0) { RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga; }
+            T x3a = (V0x - m3) * i3;
+            T s17a = (gam - m17) * i17;
+            T sinA = trig.sin(s17a), sinXa = trig.sin(x3a);
+            for (int n = 0; n < nsteps; ++n) {
+                // delay slots x16, x17 at the two ends of the step (np.roll semantics, simply.py:35-38)
+                const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
+                const T s17b = (ga - m17) * i17;
+                const T p17m = hold ? s17a : (s17a + s17b) / T(2);
+                const T arg1 = role == 0 ? th : (role == 1 ? ga : (role == 2 ? s17b : p17m));
+                T sv, cv;
+                trig.sincos(arg1, &sv, &cv);
+                const T sinB = __shfl(sv, c16 + 32, 64);
+                const T sinMr = __shfl(sv, c16 + 48, 64);
+                T x3b;
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world with the
+                    // cable axes at node n (R @ v of velocity_transform_batch.py:100-101, R composed
+                    // from the augmentation angles); only its x component feeds x3
+                    const T st = __shfl(sv, c16, 64), ct = __shfl(cv, c16, 64);
+                    const T sg = __shfl(sv, c16 + 16, 64), cg = __shfl(cv, c16 + 16, 64);
+                    const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
+                    const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+                    const T *u = &sU[c * US + n * 3];
+                    V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    x3b = (v.x - m3) * i3;
+                } else {
+                    x3b = RV_PL(sX, 0, n + 1, c);
+                }
+                const T x3m = (x3a + x3b) / T(2);                             // :62 feature midpoint
+                const T s2 = trig.sin((role & 1) ? x3m : x3b);
+                const T sinXb = __shfl(s2, c16, 64), sinXm = __shfl(s2, c16 + 16, 64);
+                const T k1t = (((sinA - sinXa) - s16a) - x3a) * KT;
+                const T k1g = (ga - m15) * i15 - s17a;
+                T thn, gan;
+                if (euler) {
+                    thn = th + k1t * a.h;                                     // main_fun.py:761
+                    gan = ga + k1g * a.h;
+                } else {
+                    const T p16m = hold ? s16a : (s16a + s16b) / T(2);
+                    const T p16e = hold ? s16a : s16b, p17e = hold ? s17a : s17b;
+                    const T sinM = hold ? sinA : sinMr;
+                    const T sinE = hold ? sinA : sinB;
+                    const T k2t = (((sinM - sinXm) - p16m) - x3m) * KT, k3t = k2t;
+                    const T k4t = (((sinE - sinXb) - p16e) - x3b) * KT;
+                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
+                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
+                    const T k4g = ((ga + a.h * k3g) - m15) * i15 - p17e;
+                    thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
+                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
+                }
+                thm = th; gam = ga; th = thn; ga = gan;
+                x3a = x3b; sinXa = sinXb; s17a = s17b; sinA = sinB;
+                if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga; }
+            }
+        }
+    } else if (tid < CK) {
         const int c = tid;
+        const int nsteps = (a.debug & 1) ? 0 : N;
         T th = th0, ga = ga0, thm = thm0, gam = gam0;
         RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
-        // COMPOSE: velocity-dependent scaled slots of node n (3..8, 13) carried in registers
-        T Vx = V0x, Vy = V0y, Vz = V0z;
-        if (VT == ROVMPC_VT_COMPOSE) {
-            const T ux = RV_PL(sA, 5, 0, c), uy = RV_PL(sA, 6, 0, c), uz = RV_PL(sA, 7, 0, c);
-            const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);
-            const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));
-            RV_PL(sX, 3, 0, c) = (Vx - a.mean[3]) * a.inv_scale[3];
-            RV_PL(sX, 4, 0, c) = (Vy - a.mean[4]) * a.inv_scale[4];
-            RV_PL(sX, 5, 0, c) = (Vz - a.mean[5]) * a.inv_scale[5];
-            RV_PL(sX, 6, 0, c) = (A0x - a.mean[6]) * a.inv_scale[6];
-            RV_PL(sX, 7, 0, c) = (A0y - a.mean[7]) * a.inv_scale[7];
-            RV_PL(sX, 8, 0, c) = (A0z - a.mean[8]) * a.inv_scale[8];
-            RV_PL(sX, 13, 0, c) = (ap - a.mean[13]) * a.inv_scale[13];
-        }
-        for (int n = 0; n < N; ++n) {
-            if (VT == ROVMPC_VT_COMPOSE) {
-                // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world,
-                // axes of the cable at node n (R @ v of velocity_transform_batch.py:100-101
-                // with R composed from the augmentation angles)
-                const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
-                const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
-                T st, ct, sg, cg;
-                m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg);
-                const T *u = &sU[c * US + n * 3];
-                V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
-                v = rodrigues_unit<T>(v, kt, st, ct);
-                const T Ax = (v.x - Vx) * a.inv_h, Ay = (v.y - Vy) * a.inv_h, Az = (v.z - Vz) * a.inv_h;
-                Vx = v.x; Vy = v.y; Vz = v.z;
-                const T ux = RV_PL(sA, 5, n + 1, c), uy = RV_PL(sA, 6, n + 1, c), uz = RV_PL(sA, 7, n + 1, c);
-                const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);
-                const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));
-                RV_PL(sX, 3, n + 1, c) = (Vx - a.mean[3]) * a.inv_scale[3];
-                RV_PL(sX, 4, n + 1, c) = (Vy - a.mean[4]) * a.inv_scale[4];
-                RV_PL(sX, 5, n + 1, c) = (Vz - a.mean[5]) * a.inv_scale[5];
-                RV_PL(sX, 6, n + 1, c) = (Ax - a.mean[6]) * a.inv_scale[6];
-                RV_PL(sX, 7, n + 1, c) = (Ay - a.mean[7]) * a.inv_scale[7];
-                RV_PL(sX, 8, n + 1, c) = (Az - a.mean[8]) * a.inv_scale[8];
-                RV_PL(sX, 13, n + 1, c) = (ap - a.mean[13]) * a.inv_scale[13];
-            }
-            // delay slots x16, x17 at the two ends of the step (np.roll semantics, simply.py:35-38)
-            const T s16a = (thm - a.mean[16]) * a.inv_scale[16], s16b = (th - a.mean[16]) * a.inv_scale[16];
-            const T s17a = (gam - a.mean[17]) * a.inv_scale[17], s17b = (ga - a.mean[17]) * a.inv_scale[17];
-            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
-
-            // one stage: f(features(y, t_n + cfrac h)); cfrac in {0, 1/2, 1}
-            auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
-                T p16, p17;
-                if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
-                else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
-                else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
-                const T x14 = (yth - a.mean[14]) * a.inv_scale[14];
-                const T x15 = (yga - a.mean[15]) * a.inv_scale[15];
-                auto exo = [&](int slot) -> T {
-                    if (cfrac2 == 0) return RV_PL(sX, slot, n, c);
-                    if (cfrac2 == 2) return RV_PL(sX, slot, n + 1, c);
-                    return (RV_PL(sX, slot, n, c) + RV_PL(sX, slot, n + 1, c)) / T(2);   // :62
-                };
-                if (MODEL == MODEL_BUILTIN) {
-                    // saved_models/equations_dtheta_dt.csv complexity 13:
-                    //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)
-                    // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
-                    const T x3 = exo(3);
-                    dth = (((m_sin(p17) - m_sin(x3)) - p16) - x3) * T(0.048152514);
-                    dga = x15 - p17;
-                } else {
-                    T *feat = sF + c;                       // [slot][lane]
-                    T *stack = sF + 18 * CK + c;
-                    for (int s = 0; s < NEXO; ++s) feat[s * CK] = exo(s);
-                    feat[14 * CK] = x14; feat[15 * CK] = x15; feat[16 * CK] = p16; feat[17 * CK] = p17;
+        const T m14 = sMean[14], i14 = sInv[14], m15 = sMean[15], i15 = sInv[15];
+        const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+        const bool euler = a.integrator == ROVMPC_EULER;
+        const T hh = T(0.5) * a.h, h6 = a.h / T(6);
+        {
+            // generic path: full 18-slot feature row per stage, bytecode interpreter
+            T Vx = V0x, Vy = V0y, Vz = V0z;
+            auto store_vslots = [&](int node, T vx, T vy, T vz, T ax, T ay, T az) {
+                const T ux = RV_PL(sA, 5, node, c), uy = RV_PL(sA, 6, node, c), uz = RV_PL(sA, 7, node, c);
+                const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
+                const T ap = m_clip((vx * ux + vy * uy + vz * uz) / nv, T(-1), T(1));
+                RV_PL(sX, 3, node, c) = (vx - sMean[3]) * sInv[3];
+                RV_PL(sX, 4, node, c) = (vy - sMean[4]) * sInv[4];
+                RV_PL(sX, 5, node, c) = (vz - sMean[5]) * sInv[5];
+                RV_PL(sX, 6, node, c) = (ax - sMean[6]) * sInv[6];
+                RV_PL(sX, 7, node, c) = (ay - sMean[7]) * sInv[7];
+                RV_PL(sX, 8, node, c) = (az - sMean[8]) * sInv[8];
+                RV_PL(sX, 13, node, c) = (ap - sMean[13]) * sInv[13];
+            };
+            if (VT == ROVMPC_VT_COMPOSE) store_vslots(0, Vx, Vy, Vz, A0x, A0y, A0z);
+            T *feat = sF + c;                       // [slot][lane]
+            T *stack = sF + 18 * CK + c;
+            for (int n = 0; n < nsteps; ++n) {
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
+                    const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+                    T st, ct, sg, cg;
+                    m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg);
+                    const T *u = &sU[c * US + n * 3];
+                    V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * a.inv_h, (v.y - Vy) * a.inv_h, (v.z - Vz) * a.inv_h);
+                    Vx = v.x; Vy = v.y; Vz = v.z;
+                }
+                const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
+                const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;
+                // one stage: f(features(y, t_n + cfrac h)); cfrac2 = 2 cfrac in {0, 1, 2}
+                auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
+                    T p16, p17;
+                    if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
+                    else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
+                    else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
+                    for (int s = 0; s < NEXO; ++s) {
+                        T v;
+                        if (cfrac2 == 0) v = RV_PL(sX, s, n, c);
+                        else if (cfrac2 == 2) v = RV_PL(sX, s, n + 1, c);
+                        else v = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);      // :62
+                        feat[s * CK] = v;
+                    }
+                    feat[14 * CK] = (yth - m14) * i14; feat[15 * CK] = (yga - m15) * i15;
+                    feat[16 * CK] = p16; feat[17 * CK] = p17;
                     dth = interp_eval<T>(a.code_th, a.n_th, a.consts, feat, CK, stack, CK);
                     dga = interp_eval<T>(a.code_ga, a.n_ga, a.consts, feat, CK, stack, CK);
+                };
+                T k1t, k1g;
+                stage(th, ga, 0, k1t, k1g);
+                T thn, gan;
+                if (euler) {
+                    thn = th + k1t * a.h;                                     // main_fun.py:761
+                    gan = ga + k1g * a.h;
+                } else {
+                    T k2t, k2g, k3t, k3g, k4t, k4g;
+                    stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
+                    stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
+                    stage(th + a.h * k3t, ga + a.h * k3g, 2, k4t, k4g);
+                    thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
+                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
-            };
-
-            T k1t, k1g;
-            stage(th, ga, 0, k1t, k1g);
-            T thn, gan;
-            if (a.integrator == ROVMPC_EULER) {
-                thn = th + k1t * a.h;                                         // main_fun.py:761
-                gan = ga + k1g * a.h;
-            } else {
-                T k2t, k2g, k3t, k3g, k4t, k4g;
-                const T hh = T(0.5) * a.h;
-                stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
-                stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
-                stage(th + a.h * k3t, ga + a.h * k3g, 2, k4t, k4g);
-                const T h6 = a.h / T(6);
-                thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);        // :66
-                gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
+                thm = th; gam = ga; th = thn; ga = gan;
+                RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
             }
-            thm = th; gam = ga; th = thn; ga = gan;
-            RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
         }
     }
     __syncthreads();
 
     // ---- phase 4: per-node geometry and cost ----------------------------------------------
-    for (int i = tid; i < N * CK; i += NT) {
+    const Trig<T> trig4(false);
+    for (int i = tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) {
         const int n = i / CK, c = i % CK;
         const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                 rz = RV_PL(sP, 2, n + 1, c) - P0z;
@@ -324,9 +416,12 @@ rollout_kernel(const RolloutArgs<T> a) {
         const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
         const T dH = a.up * rz;                                              // :293
         const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
-        const CatRoot<T> cr = solve_catenary_root<T>(l, dH, a.L, a.c_lo, a.c_hi);   // :303
-        const T Tn = cable_tension<T>(l, cr, a.w_per_len);                   // :304-305
-        const T zl = P0z + augmented_lowest_z<T>({rx, ry, rz}, th, ga, a.L, a.M, a.up, a.c_lo, a.c_hi);
+        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, a.up, trig4);
+        const T ls[2] = {l, sh.lp}, ds[2] = {dH, sh.dHp};
+        CatRoot<T> cr[2];
+        solve_catenary_roots<T, 2>(ls, ds, a.L, a.c_lo, a.c_hi, cr);         // :303 and Catenary(A, B')
+        const T Tn = cable_tension<T>(l, cr[0], a.w_per_len);                // :304-305
+        const T zl = P0z + augmented_finish<T>(sh, cr[1], a.L, a.M, a.up);
         const T eth = th - a.theta_ref, ega = ga - a.gamma_ref;
         const T e0 = u[0] - a.Uref[0], e1 = u[1] - a.Uref[1], e2 = u[2] - a.Uref[2];
         const T taut = m_max(T(0), d - a.rhoL);

@@ -26,6 +26,7 @@ struct rovmpc_handle {
     void *d_consts = nullptr;        // T
     double *d_consts64 = nullptr;    // double (utility kernels)
     void *d_Rtab = nullptr;          // T [N][9]
+    void *d_msc = nullptr;           // T: mean[18], 1/scale[18]
     bool has_rtab = false;
     // launch geometry / workspace
     int CK = 0, nblocks = 0, NT = 0;
@@ -126,9 +127,11 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     h->esz = cfg->dtype == ROVMPC_F64 ? 8 : 4;
     h->CK = pick_ck(cfg);
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
-    int items = (cfg->N + 1) * h->CK;
-    h->NT = items >= 256 ? 256 : ((items + 63) / 64) * 64;
-    if (h->NT < 64) h->NT = 64;
+    // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
+    // the per-node geometry phase is a single round
+    int items = cfg->N * h->CK;
+    h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
+    if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
     // worst-case LDS over the model/vt variants this handle may launch
     size_t need = lds_need(cfg, h->CK);
     if (need > 160 * 1024) {
@@ -163,6 +166,7 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc(&h->d_consts, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
+    CR(hipMalloc(&h->d_msc, 36 * 8));
 #undef CR
     *out = h;
     return ROVMPC_OK;
@@ -174,7 +178,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab};
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_msc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -270,6 +274,20 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
             HIPCHK(h, hipMemcpy(h->d_consts, cf.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
         }
     }
+    {
+        double msc[36];
+        for (int i = 0; i < 18; ++i) {
+            msc[i] = i < n_features ? mean[i] : 0.0;
+            msc[18 + i] = i < n_features ? 1.0 / scale[i] : 1.0;
+        }
+        if (h->cfg.dtype == ROVMPC_F64) {
+            HIPCHK(h, hipMemcpy(h->d_msc, msc, sizeof(msc), hipMemcpyHostToDevice));
+        } else {
+            float mf[36];
+            for (int i = 0; i < 36; ++i) mf[i] = (float)msc[i];
+            HIPCHK(h, hipMemcpy(h->d_msc, mf, sizeof(mf), hipMemcpyHostToDevice));
+        }
+    }
     // Fingerprint against the compiled-in rows of saved_models/equations_*.csv
     // (complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3: x15 - x17).
     bool same = n_features == 18 && !h->cfg.force_interpreter;
@@ -318,7 +336,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
     a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
-    a.prev_mode = c.prev_mode; a.integrator = c.integrator;
+    a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags;
     a.h = (T)c.dt; a.vs_h = (T)(c.v_scale * c.dt); a.inv_h = (T)(1.0 / c.dt); a.L = (T)c.L;
     a.w_per_len = (T)(c.cable_wet_weight / c.L); a.c_lo = (T)c.c_lo; a.c_hi = (T)c.c_hi;
     a.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
@@ -326,10 +344,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.w_taut = (T)c.w_taut; a.rhoL = (T)(c.rho_taut * c.L); a.w_floor = (T)c.w_floor; a.z_floor = (T)c.z_floor;
     a.theta_ref = (T)c.theta_ref; a.gamma_ref = (T)c.gamma_ref;
     for (int i = 0; i < 3; ++i) a.Uref[i] = (T)c.U_ref[i];
-    for (int i = 0; i < 18; ++i) {
-        a.mean[i] = i < h->n_feat ? (T)h->mean[i] : (T)0;
-        a.inv_scale[i] = i < h->n_feat ? (T)(1.0 / h->scale[i]) : (T)1;
-    }
+    a.msc = (const T *)h->d_msc;
 }
 
 template <typename T, int MODEL, int VT>

@@ -29,6 +29,7 @@ class MPCConfig:
     frame: str = "ENU"
     force_interpreter: bool = False
     candidates_per_block: int = 0
+    debug_flags: int = 0
     dt: float = 1.0 / 60.0
     v_scale: float = 1e-3
     L: float = 3.0
@@ -61,6 +62,7 @@ class MPCConfig:
         c.frame = _lib.ENU if self.frame == "ENU" else _lib.NED
         c.force_interpreter = int(self.force_interpreter)
         c.candidates_per_block = self.candidates_per_block
+        c.debug_flags = self.debug_flags
         for k in ("dt", "v_scale", "L", "cable_wet_weight", "c_lo", "c_hi", "w_theta", "w_gamma", "w_u", "w_T",
                   "w_taut", "rho_taut", "w_floor", "z_floor", "theta_ref", "gamma_ref"):
             setattr(c, k, float(getattr(self, k)))

@@ -88,6 +88,8 @@ typedef struct rovmpc_config {
     int32_t frame;              /* ROVMPC_ENU | ROVMPC_NED (catenary.py:10)                 */
     int32_t force_interpreter;  /* 1: never take the compiled-in default-equation path      */
     int32_t candidates_per_block; /* 0 = auto; else 1..64                                   */
+    int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
+    int32_t reserved0;
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
     double L;                   /* cable length [m] (test_cluster.py:22)                    */
