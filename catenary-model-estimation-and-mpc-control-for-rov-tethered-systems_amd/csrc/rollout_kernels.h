@@ -45,6 +45,12 @@ template <typename T> struct RolloutArgs {
     T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
     T Uref[3];
     const T *msc;             // device: mean[18] then 1/scale[18]
+    // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
+    unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
+    double *result;               // [5 + 2(N+1)]
+    long long *slots;             // [world][R] order-preserving int64 image (sharded step) or null
+    long long k_offset;
+    int rank, world;
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -94,6 +100,65 @@ RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restric
         }
     }
     return top;
+}
+
+// ---- arg-min epilogue ----------------------------------------------------------------------
+// Agent-scope (sc1, write-through / L1-bypassing) accessors for the bytes one workgroup hands
+// to another inside a launch.
+RV_DEV void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV void st_agent(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One workgroup: lexicographic (cost, index) minimum over the per-block bests, then the
+// result record [J*, k*, u(3), (theta,gamma)_0..N].  If slots != null also writes the
+// order-preserving int64 image of the record into slots[rank][*] and INT64_MAX elsewhere
+// (input of the single all-reduce(min) of the candidate-sharded step).  `scratch` = 16
+// doubles of LDS.
+template <typename T>
+RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
+                            const T *U, int N, int CK, double *result, long long k_offset,
+                            long long *slots, int rank, int world, double *scratch) {
+    double *sJ = scratch;                                    // [8]
+    long long *sK = reinterpret_cast<long long *>(scratch + 8);   // [8]
+    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    double Jd = __builtin_inf();
+    long long kk = 0x7fffffffffffffffLL;
+    for (int b = tid; b < nblocks; b += blockDim.x) {
+        const double oJ = ld_agent(&blk_cost[b]); const long long ok = ld_agent(&blk_idx[b]);
+        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double oJ = __shfl_down(Jd, off, 64);
+        const long long ok = __shfl_down(kk, off, 64);
+        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+    }
+    if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nw; ++w)
+            if (sJ[w] < Jd || (sJ[w] == Jd && sK[w] < kk)) { Jd = sJ[w]; kk = sK[w]; }
+        sK[0] = kk;
+        sJ[0] = Jd;
+    }
+    __syncthreads();
+    const long long kbest = sK[0];
+    const double Jbest = sJ[0];
+    const int R = 5 + 2 * (N + 1);
+    const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
+    for (int i = tid; i < R; i += blockDim.x) {
+        double v;
+        if (i == 0) v = Jbest;
+        else if (i == 1) v = (double)(kbest + k_offset);
+        else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
+        else v = ld_agent(&bt[i - 5]);
+        result[i] = v;
+        if (slots) slots[(size_t)rank * R + i] = ordered_key(v);
+    }
+    if (slots) {
+        for (int i = tid; i < world * R; i += blockDim.x)
+            if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
+    }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------
@@ -451,8 +516,8 @@ rollout_kernel(const RolloutArgs<T> a) {
             if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
         }
         if (c == 0) {
-            a.blk_cost[blockIdx.x] = Jd;
-            a.blk_idx[blockIdx.x] = kk;
+            st_agent(&a.blk_cost[blockIdx.x], Jd);
+            st_agent(&a.blk_idx[blockIdx.x], kk);
             *s_best_c = (int)(kk - k0);
         }
     }
@@ -461,8 +526,8 @@ rollout_kernel(const RolloutArgs<T> a) {
         const int cb = *s_best_c;
         double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
         for (int i = tid; i < (N + 1); i += NT) {
-            bt[2 * i] = (double)RV_PL(sY, 0, i, cb);
-            bt[2 * i + 1] = (double)RV_PL(sY, 1, i, cb);
+            st_agent(&bt[2 * i], (double)RV_PL(sY, 0, i, cb));
+            st_agent(&bt[2 * i + 1], (double)RV_PL(sY, 1, i, cb));
         }
         if (a.traj_all) {
             for (int i = tid; i < nvalid * (N + 1); i += NT) {
@@ -472,58 +537,31 @@ rollout_kernel(const RolloutArgs<T> a) {
             }
         }
     }
-}
+    if (!a.result) return;
 
-// ---- arg-min epilogue ----------------------------------------------------------------------
-// One workgroup: lexicographic (cost, index) minimum over the per-block bests, then the
-// result record [J*, k*, u(3), (theta,gamma)_0..N].  If slots != null also writes the
-// order-preserving int64 image of the record into slots[rank][*] and INT64_MAX elsewhere
-// (input of the single all-reduce(min) of the candidate-sharded step).
-template <typename T>
-__global__ void __launch_bounds__(256)
-finalize_kernel(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
-                const T *U, int N, int CK, double *result, long long k_offset,
-                long long *slots, int rank, int world) {
-    __shared__ double sJ[4];
-    __shared__ long long sK[4];
-    __shared__ long long s_k;
-    const int tid = threadIdx.x;
-    double Jd = __builtin_inf();
-    long long kk = 0x7fffffffffffffffLL;
-    for (int b = tid; b < nblocks; b += blockDim.x) {
-        const double oJ = blk_cost[b]; const long long ok = blk_idx[b];
-        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oJ = __shfl_down(Jd, off, 64);
-        const long long ok = __shfl_down(kk, off, 64);
-        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
-    }
-    if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
+    // ---- arg-min epilogue in the last workgroup to arrive ------------------------------------
+    // Hand-off (cdna_hip_programming.md G16, counter form): every handed-off byte is stored
+    // write-through at agent scope (sc1), every storing wave drains its stores, the workgroup
+    // meets at a barrier, ONE lane takes a ticket; the workgroup that draws the last ticket
+    // acquires at agent scope and reads with agent-scope (sc1) loads.  No assumption on
+    // dispatch order or XCD placement.  The ticket counter is monotone (never reset): every
+    // launch of this handle adds exactly gridDim.x.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int *s_last = s_best_c + 1;
     if (tid == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-            if (sJ[w] < Jd || (sJ[w] == Jd && sK[w] < kk)) { Jd = sJ[w]; kk = sK[w]; }
-        s_k = kk;
-        sJ[0] = Jd;
+        const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = ((old + 1ULL) % (unsigned long long)gridDim.x) == 0ULL;
     }
     __syncthreads();
-    const long long kbest = s_k;
-    const int R = 5 + 2 * (N + 1);
-    const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
-    for (int i = tid; i < R; i += blockDim.x) {
-        double v;
-        if (i == 0) v = sJ[0];
-        else if (i == 1) v = (double)(kbest + k_offset);
-        else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
-        else v = bt[i - 5];
-        result[i] = v;
-        if (slots) slots[(size_t)rank * R + i] = ordered_key(v);
+    if (!*s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (slots) {
-        for (int i = tid; i < world * R; i += blockDim.x)
-            if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
-    }
+    __syncthreads();
+    argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, (int)gridDim.x, a.U, N, CK, a.result, a.k_offset,
+                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4));
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

@@ -34,6 +34,7 @@ struct rovmpc_handle {
     void *d_U = nullptr, *d_J = nullptr, *d_traj_all = nullptr;
     double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
     long long *d_blk_idx = nullptr;
+    unsigned long long *d_ticket = nullptr;
     double *h_result = nullptr;      // pinned
     // timing
     std::vector<hipEvent_t> ev;
@@ -85,9 +86,10 @@ static size_t lds_need(const rovmpc_config *c, int ck) {
 
 static int pick_ck(const rovmpc_config *c) {
     if (c->candidates_per_block > 0) return c->candidates_per_block;
-    int ck = 1;
-    while (ck < 16 && c->K / (ck * 2) >= 1024) ck *= 2;     // aim at ~4 resident workgroups per CU
-    while (ck > 1 && lds_need(c, ck) > 40 * 1024) ck /= 2;   // and keep 4 of them inside 160 KiB of LDS
+    // 16 candidates x 4 role lanes fill one wave in the sequential phase of the compiled-in
+    // model; shrink only to keep two workgroups per CU inside the 160 KiB of LDS
+    int ck = 16;
+    while (ck > 1 && lds_need(c, ck) > 64 * 1024) ck /= 2;
     return ck;
 }
 
@@ -167,6 +169,8 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
     CR(hipMalloc(&h->d_msc, 36 * 8));
+    CR(hipMalloc((void **)&h->d_ticket, sizeof(unsigned long long)));
+    CR(hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
 #undef CR
     *out = h;
     return ROVMPC_OK;
@@ -178,7 +182,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_msc};
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_msc, h->d_ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -345,6 +349,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.theta_ref = (T)c.theta_ref; a.gamma_ref = (T)c.gamma_ref;
     for (int i = 0; i < 3; ++i) a.Uref[i] = (T)c.U_ref[i];
     a.msc = (const T *)h->d_msc;
+    a.ticket = h->d_ticket;
 }
 
 template <typename T, int MODEL, int VT>
@@ -360,9 +365,11 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, hi
 }
 
 template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h, const double *d_state, const void *d_U,
-                                                         void *d_traj_all, hipStream_t s) {
+                                                         void *d_traj_all, double *d_result, long long k_offset,
+                                                         long long *d_slots, int rank, int world, hipStream_t s) {
     RolloutArgs<T> a;
     fill_args<T>(h, a, d_state, d_U, d_traj_all);
+    a.result = d_result; a.k_offset = k_offset; a.slots = d_slots; a.rank = rank; a.world = world;
     const int vt = h->cfg.vt_mode;
     if (h->builtin) {
         if (vt == 0) return launch_one<T, MODEL_BUILTIN, 0>(h, a, s);
@@ -387,20 +394,11 @@ static int enqueue_step(rovmpc_handle *h, const double *d_state, const void *d_U
     if (rc) return rc;
     const bool time_it = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (time_it) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], s));
-    hipError_t e = h->cfg.dtype == ROVMPC_F64 ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, s)
-                                              : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, s);
+    hipError_t e = h->cfg.dtype == ROVMPC_F64
+                       ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s)
+                       : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s);
     if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     if (time_it) { HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
-    if (d_result) {
-        if (h->cfg.dtype == ROVMPC_F64)
-            hipLaunchKernelGGL(finalize_kernel<double>, dim3(1), dim3(256), 0, s, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                               h->nblocks, (const double *)d_U, h->cfg.N, h->CK, d_result, k_offset, d_slots, rank, world);
-        else
-            hipLaunchKernelGGL(finalize_kernel<float>, dim3(1), dim3(256), 0, s, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                               h->nblocks, (const float *)d_U, h->cfg.N, h->CK, d_result, k_offset, d_slots, rank, world);
-        e = hipGetLastError();
-        if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "finalize kernel launch failed: %s", hipGetErrorString(e));
-    }
     return ROVMPC_OK;
 }
 
