@@ -1,0 +1,222 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every symbol the header
+declares, the expression compiler, the model loader, the trajectory generator, the feature map,
+and the loud failure without a GPU.  No compute call into the library happens here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rovmpc
+from rovmpc import expr as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rovmpc.h")).read()
+    declared = set(re.findall(r"\b(rovmpc_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 22
+    assert declared == set(rovmpc.exported_symbols())
+    lib = rovmpc.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.rovmpc_version()
+
+
+def test_config_struct_matches_c_layout():
+    lib = rovmpc.load_library()
+    from rovmpc._lib import Config
+    c = Config()
+    lib.rovmpc_default_config(ctypes.byref(c))
+    assert c.struct_size == ctypes.sizeof(Config)
+    assert (c.N, c.K, c.n_shape_pts) == (20, 4096, 16)
+    assert c.dt == pytest.approx(1 / 60) and c.L == 3.0 and c.cable_wet_weight == 1.521
+    assert c.c_lo == 1e-6 and c.c_hi == 10.0 and c.rho_taut == 0.98
+    py = rovmpc.MPCConfig().to_c()
+    for f, _ in Config._fields_:
+        if f in ("U_ref",):
+            continue
+        assert getattr(py, f) == getattr(c, f), f
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="needs a box without a GPU")
+def test_no_gpu_is_a_loud_error_not_a_fallback():
+    with pytest.raises(rovmpc.RovmpcError) as ei:
+        rovmpc.Engine()
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+    with pytest.raises(rovmpc.RovmpcError):
+        rovmpc.solve_catenary([1.0], [0.0], 3.0)
+    with pytest.raises(rovmpc.RovmpcError):
+        rovmpc.MPC(N=4, K=8)
+
+
+def test_missing_library_is_a_loud_error(tmp_path):
+    from rovmpc import _lib
+    with pytest.raises(rovmpc.RovmpcError):
+        _lib.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "catenary-model-estimation-and-mpc-control-for-rov-tethered-systems_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+(oracle|scipy|sympy)", txt, re.M), f
+                assert "rovmpc_oracle" not in txt, f
+
+
+# ---- expression compiler -------------------------------------------------------------------
+
+def _run(program, consts, x):
+    """Tiny host interpreter of the bytecode (test-only) to check the compiler's output."""
+    inv = {v: k for k, v in E.OP.items()}
+    st = []
+    for ins in program.code:
+        op, arg = inv[ins & 0xFF], ins >> 8
+        if op == "PUSH_C":
+            st.append(consts[arg])
+        elif op == "PUSH_F":
+            st.append(x[arg])
+        elif op in ("ADD", "SUB", "MUL", "DIV", "POW"):
+            b = st.pop(); a = st.pop()
+            st.append({"ADD": a + b, "SUB": a - b, "MUL": a * b, "DIV": a / b, "POW": a ** b}[op])
+        elif op == "POWI":
+            e = arg - (1 << 24) if arg >= (1 << 23) else arg
+            st.append(st.pop() ** e)
+        else:
+            v = st.pop()
+            st.append({"NEG": -v, "SIN": np.sin(v), "COS": np.cos(v), "TANH": np.tanh(v), "ABS": abs(v),
+                       "SQUARE": v * v, "EXP": np.exp(v), "LOG": np.log(v), "SQRT": np.sqrt(v),
+                       "SAFE_LOG": np.log(abs(v) + 1e-5), "SAFE_SQRT": np.sqrt(abs(v))}[op])
+    assert len(st) == 1
+    return st[0]
+
+
+def test_compiler_reproduces_every_reference_row(golden_dir, equations):
+    g = np.load(os.path.join(golden_dir, "kat_dynamics.npz"))
+    for which, key in (("dtheta_dt", "out_theta"), ("dgamma_dt", "out_gamma")):
+        for i, row in enumerate(equations[which]["rows"]):
+            consts = []
+            prog = E.compile_expression(row["sympy_format"], consts)
+            for j in (0, 17, 101, 255):
+                got = _run(prog, consts, g["Xs"][j])
+                assert got == pytest.approx(g[key][i][j], rel=1e-12, abs=1e-15)
+            # the PySR-style "equation" column compiles to the same function
+            prog2 = E.compile_expression(row["equation"], consts)
+            assert _run(prog2, consts, g["Xs"][3]) == pytest.approx(g[key][i][3], rel=1e-6, abs=1e-12)
+
+
+def test_compiler_operator_vocabulary_and_errors():
+    consts = []
+    x = np.linspace(0.1, 1.9, 18)
+    cases = {
+        "exp(x0) + log(x1) - sqrt(x2)": np.exp(x[0]) + np.log(x[1]) - np.sqrt(x[2]),
+        "safe_log(-x3) * safe_sqrt(-x4)": np.log(x[3] + 1e-5) * np.sqrt(x[4]),
+        "neg(square(x5)) / cos(x6)": -(x[5] ** 2) / np.cos(x[6]),
+        "x7**3 + x8**-2 + x9**0.5 + x10^2": x[7] ** 3 + x[8] ** -2 + x[9] ** 0.5 + x[10] ** 2,
+        "-(-x11) + +x12 - -1.5": x[11] + x[12] + 1.5,
+        "Abs(x13 - 3) * tanh(x14)": abs(x[13] - 3) * np.tanh(x[14]),
+    }
+    for text, want in cases.items():
+        assert _run(E.compile_expression(text, consts), consts, x) == pytest.approx(want, rel=1e-14)
+    p = E.compile_expression("theta*2 + gamma_prev", consts, variable_names=rovmpc.FEATURE_NAMES_GEN1)
+    assert p.features_used == [14, 17]
+    assert "PUSH_F x14" in E.disassemble(p, consts)
+    for bad in ("x1 +", "foo(x1)", "x99", "x1 if x2 else x3", "x1 < x2", "__import__('os')", "x1.real", "y"):
+        with pytest.raises(E.ExpressionError):
+            E.compile_expression(bad, consts)
+    deep = "x0" + "".join(f"+(x{i % 18}*(x1" for i in range(20)) + "))" * 20
+    with pytest.raises(E.ExpressionError):
+        E.compile_expression(deep, consts)
+
+
+def test_default_model_is_the_reference_selection(equations, scaler):
+    m = rovmpc.default_model()
+    assert m.n_features == 18
+    assert m.expr_theta == [r for r in equations["dtheta_dt"]["rows"] if r["complexity"] == 13][0]["sympy_format"]
+    assert m.expr_gamma == "x15 - x17"
+    np.testing.assert_array_equal(m.mean, scaler[0]); np.testing.assert_array_equal(m.scale, scaler[1])
+    assert rovmpc.default_model(30, 27).prog_theta.max_stack <= 16
+    with pytest.raises(KeyError):
+        rovmpc.default_model(14, 3)
+
+
+def test_load_model_dir_formats(tmp_path, equations, scaler):
+    import csv
+    import json
+    d = tmp_path / "saved_models"; d.mkdir()
+    for which in ("dtheta_dt", "dgamma_dt"):
+        with open(d / f"equations_{which}.csv", "w", newline="") as f:
+            w = csv.writer(f); w.writerow(["complexity", "loss", "score", "equation", "sympy_format", "lambda_format"])
+            for r in equations[which]["rows"]:
+                w.writerow([r["complexity"], r["loss"], r["score"], r["equation"], r["sympy_format"], "PySRFunction(...)"])
+        c = equations[which]["chosen_complexity"]
+        (d / f"eq_{which}.txt").write_text(f"complexity   {c:>50}\nloss   0.0\nequation   ((((sin(x17) - sin(x3)) ...\n")
+    json.dump({"mean": scaler[0].tolist(), "scale": scaler[1].tolist()}, open(d / "scaler.json", "w"))
+    m = rovmpc.load_model_dir(str(d))
+    assert m.expr_gamma == "x15 - x17" and "sin(x17)" in m.expr_theta
+    m2 = rovmpc.load_model_dir(str(d), complexity_theta=5, complexity_gamma=9)
+    assert m2.prog_theta.features_used == [3, 17]
+    # PySR hall_of_fame layout (Complexity,Loss,Equation)
+    with open(d / "hall_of_fame.csv", "w") as f:
+        f.write("Complexity,Loss,Equation\n3,0.1,(x15 - x17)\n5,0.05,((x15 - x17) * 1.18)\n")
+    rows = rovmpc.read_equation_csv(str(d / "hall_of_fame.csv"))
+    assert rows[1]["complexity"] == 5 and rows[1]["sympy_format"] == "((x15 - x17) * 1.18)"
+
+
+# ---- trajectory generator, feature map -------------------------------------------------------
+
+@pytest.mark.parametrize("case", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14])
+def test_trajectory_generator_matches_reference_csv(golden_dir, case):
+    text = open(os.path.join(golden_dir, f"rov_trajectory_exp{case}.csv")).read()
+    _, a, b = rovmpc.generate_rov_trajectories(case, 100, 10.0)
+    got = rovmpc.trajectory_csv(a, b)
+    assert got.split("\n")[0] == text.split("\n")[0]                     # header verbatim
+    G = np.array([[float(v) for v in r.split(",")] for r in got.strip().split("\n")[1:]])
+    W = np.array([[float(v) for v in r.split(",")] for r in text.strip().split("\n")[1:]])
+    np.testing.assert_allclose(G, W, atol=1.0001e-3, rtol=0)
+    assert (G != W).mean() < 0.01
+
+
+def test_trajectory_generator_seeded_cases_and_scaling():
+    _, a1, b1 = rovmpc.generate_rov_trajectories(10, 500, 10.0, seed=3)
+    _, a2, b2 = rovmpc.generate_rov_trajectories(10, 500, 10.0, seed=3)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    assert set(np.unique(a1[0])) == {-0.1, 0.1}
+    t, a, b = rovmpc.generate_rov_trajectories(12, 10000, 100.0)
+    assert a.shape == (12, 10000) and t[-1] == 100.0
+    np.testing.assert_allclose(np.hypot(a[0], a[1]), 0.4, rtol=1e-12)
+    with pytest.raises(ValueError):
+        rovmpc.generate_rov_trajectories(15)
+
+
+def test_feature_map(golden_dir):
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "kat_features.npz"))
+    df = pd.DataFrame(g["frame"], columns=[str(c) for c in g["columns"]])
+    np.testing.assert_allclose(rovmpc.extract_features(df), g["X18"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(rovmpc.extract_features(df, with_prev=False), g["X16"], rtol=1e-13, atol=1e-15)
+
+
+def test_state_and_shape_validation():
+    s = rovmpc.MPCState(P1=(1, 2, 3), theta=0.1, gamma=0.2)
+    a = s.as_array()
+    assert a.shape == (16,) and a[14] == 0.1 and a[15] == 0.2
+    assert np.array_equal(rovmpc.state_array(dict(P1=(1, 2, 3), theta=0.1, gamma=0.2)), a)
+    with pytest.raises(ValueError):
+        rovmpc.state_array(np.zeros(5))
+    with pytest.raises(ValueError):
+        rovmpc.MPCConfig(dtype="f16").to_c()
+    st, U = rovmpc.synthetic_problem(8, 5)
+    assert st.shape == (16,) and U.shape == (8, 5, 3)
