@@ -215,9 +215,28 @@ rollout_kernel(const RolloutArgs<T> a) {
     {
         const T *src = a.U + (size_t)k0 * N * 3;
         const int tot = nvalid * N * 3;
-        for (int i = tid; i < CK * N * 3; i += NT) {
-            const int c = i / (3 * N), j = i - c * (3 * N);
-            sU[c * US + j] = (i < tot) ? src[i] : T(0);
+        constexpr int VW = 16 / sizeof(T);           // elements per 16-byte lane load
+        const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (tot % VW == 0);
+        if (vec) {
+            typedef T vecT __attribute__((ext_vector_type(VW)));
+            const vecT *src4 = reinterpret_cast<const vecT *>(src);
+            for (int i = tid; i < tot / VW; i += NT) {
+                const vecT v = src4[i];
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    const int g = i * VW + e, c = g / (3 * N), j = g - c * (3 * N);
+                    sU[c * US + j] = v[e];
+                }
+            }
+            for (int i = tot + tid; i < CK * N * 3; i += NT) {
+                const int c = i / (3 * N), j = i - c * (3 * N);
+                sU[c * US + j] = T(0);
+            }
+        } else {
+            for (int i = tid; i < CK * N * 3; i += NT) {
+                const int c = i / (3 * N), j = i - c * (3 * N);
+                sU[c * US + j] = (i < tot) ? src[i] : T(0);
+            }
         }
         if (tid < 18) { sMean[tid] = a.msc[tid]; sInv[tid] = a.msc[18 + tid]; }
     }

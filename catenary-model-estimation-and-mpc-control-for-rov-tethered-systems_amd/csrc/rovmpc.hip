@@ -78,24 +78,36 @@ extern "C" const char *rovmpc_last_error(const rovmpc_handle *h) {
 
 extern "C" int32_t rovmpc_result_len(const rovmpc_handle *h) { return h ? 5 + 2 * (h->cfg.N + 1) : 0; }
 
-static size_t lds_need(const rovmpc_config *c, int ck) {
-    // worst case over the model variants this handle may launch
-    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, MODEL_INTERP, c->vt_mode) * sizeof(double)
-                                  : rollout_lds_elems<float>(c->N, ck, MODEL_INTERP, c->vt_mode) * sizeof(float);
+static size_t lds_need(const rovmpc_config *c, int ck, int model) {
+    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, model, c->vt_mode) * sizeof(double)
+                                  : rollout_lds_elems<float>(c->N, ck, model, c->vt_mode) * sizeof(float);
 }
 
-static int pick_ck(const rovmpc_config *c) {
+static int pick_ck(const rovmpc_config *c, int model) {
     if (c->candidates_per_block > 0) return c->candidates_per_block;
     // 16 candidates x 4 role lanes fill one wave in the sequential phase of the compiled-in
     // model; shrink only to keep two workgroups per CU inside the 160 KiB of LDS
     int ck = 16;
-    while (ck > 1 && lds_need(c, ck) > 64 * 1024) ck /= 2;
+    while (ck > 1 && lds_need(c, ck, model) > 64 * 1024) ck /= 2;
     return ck;
 }
 
-template <typename T> static size_t lds_bytes_for(const rovmpc_handle *h, int model, int vt) {
-    return rollout_lds_elems<T>(h->cfg.N, h->CK, model, vt) * sizeof(T);
+// Launch geometry for the model variant in use.  The per-block buffers are allocated for the
+// worst case (one candidate per workgroup) so re-deciding it at set_model needs no allocation.
+static const char *configure_geometry(rovmpc_handle *h, int model) {
+    const rovmpc_config *cfg = &h->cfg;
+    h->CK = pick_ck(cfg, model);
+    h->nblocks = (cfg->K + h->CK - 1) / h->CK;
+    // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
+    // the per-node geometry phase is a single round
+    int items = cfg->N * h->CK;
+    h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
+    if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
+    if (lds_need(cfg, h->CK, model) > 160 * 1024)
+        return "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
+    return nullptr;
 }
+
 
 extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *nullh = nullptr;
@@ -127,20 +139,12 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *h = new rovmpc_handle();
     h->cfg = *cfg;
     h->esz = cfg->dtype == ROVMPC_F64 ? 8 : 4;
-    h->CK = pick_ck(cfg);
-    h->nblocks = (cfg->K + h->CK - 1) / h->CK;
-    // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
-    // the per-node geometry phase is a single round
-    int items = cfg->N * h->CK;
-    h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
-    if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
-    // worst-case LDS over the model/vt variants this handle may launch
-    size_t need = lds_need(cfg, h->CK);
-    if (need > 160 * 1024) {
-        g_create_error = "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
+    if (const char *why = configure_geometry(h, MODEL_INTERP)) {
+        g_create_error = why;
         delete h;
         return ROVMPC_ERR_INVALID;
     }
+    const int max_blocks = cfg->candidates_per_block > 0 ? h->nblocks : cfg->K;
 #define CR(call)                                                                         \
     do {                                                                                 \
         hipError_t _e = (call);                                                          \
@@ -158,9 +162,9 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc(&h->d_U, (size_t)cfg->K * cfg->N * 3 * h->esz));
     CR(hipMalloc(&h->d_J, (size_t)cfg->K * h->esz));
     CR(hipMalloc((void **)&h->d_state, ROVMPC_STATE_LEN * sizeof(double)));
-    CR(hipMalloc((void **)&h->d_blk_cost, h->nblocks * sizeof(double)));
-    CR(hipMalloc((void **)&h->d_blk_idx, h->nblocks * sizeof(long long)));
-    CR(hipMalloc((void **)&h->d_blk_traj, (size_t)h->nblocks * (cfg->N + 1) * 2 * sizeof(double)));
+    CR(hipMalloc((void **)&h->d_blk_cost, max_blocks * sizeof(double)));
+    CR(hipMalloc((void **)&h->d_blk_idx, max_blocks * sizeof(long long)));
+    CR(hipMalloc((void **)&h->d_blk_traj, (size_t)max_blocks * (cfg->N + 1) * 2 * sizeof(double)));
     CR(hipMalloc((void **)&h->d_result, R * sizeof(double)));
     CR(hipHostMalloc((void **)&h->h_result, R * sizeof(double), hipHostMallocDefault));
     CR(hipMalloc((void **)&h->d_code_th, ROVMPC_MAX_CODE * sizeof(int32_t)));
@@ -311,6 +315,10 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
         }
     }
     h->builtin = same;
+    if (const char *why = configure_geometry(h, same ? MODEL_BUILTIN : MODEL_INTERP)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
+    // the ticket counter counts modulo the grid size: restart it with the new geometry
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
     h->has_model = true;
     return ROVMPC_OK;
 }
