@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--ck", type=int, default=0, help="candidates per workgroup (0 = auto)")
     ap.add_argument("--pools", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent MPC steps in flight on one GPU (one engine handle + HIP stream each); 1 = strictly sequential steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
@@ -99,7 +101,9 @@ def main():
 
     cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
                            candidates_per_block=args.ck, force_interpreter=args.interp, debug_flags=args.debug_flags)
-    eng = rovmpc.Engine(cfg)
+    S = max(1, args.streams) if world == 1 else 1
+    engines = [rovmpc.Engine(cfg) for _ in range(S)]
+    eng = engines[0]
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     pools = []
     for p in range(args.pools):
@@ -109,14 +113,17 @@ def main():
     d_state = torch.tensor(state, device=dev)
     R = eng.result_len
     stream = torch.cuda.current_stream()
+    streams = [stream] if S == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
     smpc = ShardedMPC(eng, rank=rank, world=world) if world > 1 else None
-    d_res = torch.empty((2, R), dtype=torch.float64, device=dev)
+    d_res = torch.empty((2 * S, R), dtype=torch.float64, device=dev)
 
     def one_step(i):
         if smpc is not None:
             return smpc.step_device(d_state, pools[i % args.pools])
-        eng.step_device(d_state.data_ptr(), pools[i % args.pools].data_ptr(), d_res[i & 1].data_ptr(), stream.cuda_stream)
-        return d_res[i & 1]
+        j = i % S
+        engines[j].step_device(d_state.data_ptr(), pools[i % args.pools].data_ptr(), d_res[i % (2 * S)].data_ptr(),
+                               streams[j].cuda_stream)
+        return d_res[i % (2 * S)]
 
     def fence():
         if smpc is not None:
@@ -132,16 +139,21 @@ def main():
     # HIP events on the launch stream bracket the timed region: with one fused kernel per step,
     # back to back on one stream, (event span) / steps is the average launch-to-launch period of
     # the rollout kernel (its duration plus the ~1.5 us dependent-launch boundary).
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     fence()
     t0 = time.perf_counter()
-    ev0.record(stream)
+    for e, st in zip(ev0, streams):
+        e.record(st)
     for i in range(args.steps):
         rec = one_step(i)
-    ev1.record(stream)
+    for e, st in zip(ev1, streams):
+        e.record(st)
     fence()
     elapsed = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)
+    # per stream: event span / launches on that stream = launch-to-launch period of the kernel
+    launches = [len(range(j, args.steps, S)) for j in range(S)]
+    region_ms = sum(a_.elapsed_time(b_) / max(n_, 1) for a_, b_, n_ in zip(ev0, ev1, launches)) / S * args.steps
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,7 +166,7 @@ def main():
     if not args.no_kernel_timing:
         n_ev = min(args.steps, 200)
         eng.timing_enable(n_ev)
-        for i in range(n_ev):
+        for i in range(n_ev * S):
             one_step(i)
         fence()
         kev_ms, kev_min_ms, _ = eng.timing_read()
@@ -178,6 +190,7 @@ def main():
                        "n_shape_pts": cfg.n_shape_pts, "vt_mode": "compose", "dt": cfg.dt,
                        "model": "compiled-in saved_models rows (13/3)" if not args.interp else "bytecode interpreter",
                        "parallelism": f"candidate-sharded x{world}, 1 all-reduce(min)/step" if world > 1 else "single GPU",
+                       "steps_in_flight": S if world == 1 else "rollout(i+1) overlaps all-reduce(i)",
                        "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
             "best": {"cost": float(last[0]), "index": int(last[1])},
         }
@@ -186,6 +199,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "rollout_kernel", "kernel_avg_us": kavg_ms * 1e3,
+                               "chip_algorithmic_GBps": alg_bytes * args.steps / elapsed / 1e9,
                                "kernel_event_pair_us": kev_ms * 1e3 if kev_ms else None,
                                "kernel_event_pair_min_us": kev_min_ms * 1e3 if kev_min_ms else None,
                                "algorithmic_bytes_per_launch": alg_bytes,
@@ -197,7 +211,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engines:
+        e.close()
 
 
 if __name__ == "__main__":

@@ -29,9 +29,20 @@ constexpr int MODEL_INTERP  = 1;   // any bytecode
 constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
 constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + unit_rel (x,y,z)
 
+// Scalars of one handle, resident in device memory and read with scalar loads where they are
+// used.  Passing them by value as kernel arguments kept ~60 SGPRs live across the whole kernel
+// and pushed the sequential phase's loop into SGPR spills (v_writelane/v_readlane per step).
+template <typename T> struct RolloutConsts {
+    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up;
+    T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
+    T Uref[3];
+    T mean[18], inv_scale[18];
+};
+
 template <typename T> struct RolloutArgs {
     const T *U;               // [K][N][3]
     const double *state;      // 16 doubles (rovmpc_state)
+    const RolloutConsts<T> *k;
     const int32_t *code_th, *code_ga;
     const T *consts;
     const T *Rtab;            // [N][9] (VT_TABLE)
@@ -41,16 +52,13 @@ template <typename T> struct RolloutArgs {
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug;
-    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up;
-    T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
-    T Uref[3];
-    const T *msc;             // device: mean[18] then 1/scale[18]
     // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
     unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
     double *result;               // [5 + 2(N+1)]
     long long *slots;             // [world][R] order-preserving int64 image (sharded step) or null
     long long k_offset;
     int rank, world;
+    unsigned long long *stamps;   // diagnostic build only (-DROVMPC_STAMPS): [nblocks][8] 100 MHz ticks
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -163,6 +171,14 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
 
 // ---- the kernel ---------------------------------------------------------------------------
 
+// In-kernel phase stamps exist only in the diagnostic library (make diag, -DROVMPC_STAMPS); the
+// product library contains none of this code.
+#ifdef ROVMPC_STAMPS
+#define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define RV_STAMP(i) do { } while (0)
+#endif
+
 // LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
 #define RV_PL(base, p, n, c) (base)[((p) * (N + 1) + (n)) * CK + (c)]
 
@@ -193,6 +209,7 @@ rollout_kernel(const RolloutArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
     const int N = a.N, CK = a.CK, K = a.K;
+    const RolloutConsts<T> &kk = *a.k;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int k0 = blockIdx.x * CK;
     const int nvalid = min(CK, K - k0);
@@ -211,6 +228,7 @@ rollout_kernel(const RolloutArgs<T> a) {
     T *sC = sU + CK * US;                            // [n][c] node costs
     T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
 
+    RV_STAMP(0);
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
     {
         const T *src = a.U + (size_t)k0 * N * 3;
@@ -238,7 +256,7 @@ rollout_kernel(const RolloutArgs<T> a) {
                 sU[c * US + j] = (i < tot) ? src[i] : T(0);
             }
         }
-        if (tid < 18) { sMean[tid] = a.msc[tid]; sInv[tid] = a.msc[18 + tid]; }
+        if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
     }
     // state (uniform loads)
     const double *sd = a.state;
@@ -248,18 +266,25 @@ rollout_kernel(const RolloutArgs<T> a) {
     const T th0 = (T)sd[12], ga0 = (T)sd[13], thm0 = (T)sd[14], gam0 = (T)sd[15];
     __syncthreads();
 
+    RV_STAMP(1);
     // ---- phase 1: position prefix along the horizon ---------------------------------------
     if (tid < 3 * CK) {
         const int ax = tid / CK, c = tid % CK;
         T p = (T)sd[3 + ax];
         RV_PL(sP, ax, 0, c) = p;
+        // sequential sum in the reference's order; the next control is read one step ahead so
+        // the LDS latency stays off the dependent add
+        T unext = sU[c * US + ax];
         for (int n = 0; n < N; ++n) {
-            p = p + a.vs_h * sU[c * US + n * 3 + ax];
+            const T ucur = unext;
+            if (n + 1 < N) unext = sU[c * US + (n + 1) * 3 + ax];
+            p = p + kk.vs_h * ucur;
             RV_PL(sP, ax, n + 1, c) = p;
         }
     }
     __syncthreads();
 
+    RV_STAMP(2);
     // ---- phase 2: exogenous feature rows of every node ------------------------------------
     // V_n (feature-frame velocity at node n) when it does not depend on (theta, gamma)
     auto vel = [&](int c, int node, T &vx, T &vy, T &vz) {
@@ -309,7 +334,7 @@ rollout_kernel(const RolloutArgs<T> a) {
             vel(c, n, Vx, Vy, Vz);
             T Ax, Ay, Az;
             if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
-            else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * a.inv_h; Ay = (Vy - Wy) * a.inv_h; Az = (Vz - Wz) * a.inv_h; }
+            else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * kk.inv_h; Ay = (Vy - Wy) * kk.inv_h; Az = (Vz - Wz) * kk.inv_h; }
             const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
             const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));   // :31
             RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
@@ -323,21 +348,44 @@ rollout_kernel(const RolloutArgs<T> a) {
     }
     __syncthreads();
 
-    // ---- phase 3: closed-loop integration of (theta, gamma) -------------------------------
+    RV_STAMP(3);
+    // ---- phase 3: closed-loop integration of (theta, gamma), with the state-independent half of
+    // the per-node geometry (phase 4a) running beside it on the workgroup's other waves --------
+
+    // phase 4a, item (n, c): node n+1 of candidate c.  Nothing here depends on (theta, gamma):
+    // catenary parameter + tension of the straight geometry (main_fun.py:292-293, 303-305),
+    // tautness and control terms of the cost.
+    auto geometry_a = [&](int first, int stride) {
+        for (int i = first; i < ((a.debug & 2) ? 0 : N * CK); i += stride) {
+            const int n = i / CK, c = i % CK;
+            const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
+                    rz = RV_PL(sP, 2, n + 1, c) - P0z;
+            const T *u = &sU[c * US + n * 3];
+            const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
+            const T dH = kk.up * rz;                                              // :293
+            const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
+            const CatRoot<T> cr = solve_catenary_root<T>(l, dH, kk.L, kk.c_lo, kk.c_hi);   // :303
+            const T Tn = cable_tension<T>(l, cr, kk.w_per_len);                   // :304-305
+            const T e0 = u[0] - kk.Uref[0], e1 = u[1] - kk.Uref[1], e2 = u[2] - kk.Uref[2];
+            const T taut = m_max(T(0), d - kk.rhoL);
+            sC[n * CK + c] = kk.w_u * (e0 * e0 + e1 * e1 + e2 * e2) + kk.w_T * Tn + kk.w_taut * (taut * taut);
+        }
+    };
+
     if (MODEL == MODEL_BUILTIN) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
         // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
         // Of the 18 slots only x3, x15, x16, x17 are read, and every sine argument of a step is
         // known once (theta_n, gamma_n) are.  The phase is sequential in n and issue-bound on
-        // fp64 trig, so each candidate gets FOUR lanes (c + 16 j, j = role): the four
+        // fp64 trig, so each candidate gets FOUR lanes (c + 16 j, j = role = wave row): the four
         // trigonometric evaluations that open a step -- sincos(theta_n), sincos(gamma_n),
         // sin(x17 at t_n+1), sin(x17 at the midpoint) -- run as ONE sincos over the wave, the two
-        // that close it -- sin(x3 at t_n+1), sin(x3 at the midpoint) -- as one more; results
-        // move between a candidate's lanes with ds_bpermute.  All four lanes carry the
+        // that close it -- sin(x3 at t_n+1), sin(x3 at the midpoint) -- as one more; the row
+        // values reach the other rows through v_permlane16/32_swap.  All four lanes carry the
         // (cheap) state update redundantly, so no other exchange is needed.
-        const int nwaves3 = (CK + 15) / 16;
-        if (tid < nwaves3 * 64) {
+        const int nint = ((CK + 15) / 16) * 64;
+        auto integrate = [&]() {
             const int lane = tid & 63, c16 = lane & 15, role = lane >> 4;
             const int cc = (tid >> 6) * 16 + c16;               // candidate of this lane
             const bool live = cc < CK;
@@ -348,13 +396,26 @@ rollout_kernel(const RolloutArgs<T> a) {
             const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
             const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
             const bool euler = a.integrator == ROVMPC_EULER;
-            const T hh = T(0.5) * a.h, h6 = a.h / T(6);
+            const T hh = T(0.5) * kk.h, h6 = kk.h / T(6);
             const T KT = T(0.048152514);
             T th = th0, ga = ga0, thm = thm0, gam = gam0;
             if (live && role == 0) { RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga; }
             T x3a = (V0x - m3) * i3;
             T s17a = (gam - m17) * i17;
             T sinA = trig.sin(s17a), sinXa = trig.sin(x3a);
+            // operands of the velocity transform of step 0 (prefetched one step ahead below)
+            T ktx = T(0), kty = T(0), kgx = T(0), kgy = T(0), kgz = T(0), u0 = T(0), u1 = T(0), u2 = T(0), x3n = T(0);
+            auto fetch = [&](int n) {
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    ktx = RV_PL(sA, 0, n, c); kty = RV_PL(sA, 1, n, c);
+                    kgx = RV_PL(sA, 2, n, c); kgy = RV_PL(sA, 3, n, c); kgz = RV_PL(sA, 4, n, c);
+                    const T *u = &sU[c * US + n * 3];
+                    u0 = u[0]; u1 = u[1]; u2 = u[2];
+                } else {
+                    x3n = RV_PL(sX, 0, n + 1, c);
+                }
+            };
+            if (nsteps > 0) fetch(0);
             for (int n = 0; n < nsteps; ++n) {
                 // delay slots x16, x17 at the two ends of the step (np.roll semantics, simply.py:35-38)
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
@@ -363,33 +424,35 @@ rollout_kernel(const RolloutArgs<T> a) {
                 const T arg1 = role == 0 ? th : (role == 1 ? ga : (role == 2 ? s17b : p17m));
                 T sv, cv;
                 trig.sincos(arg1, &sv, &cv);
-                const T sinB = __shfl(sv, c16 + 32, 64);
-                const T sinMr = __shfl(sv, c16 + 48, 64);
+                T sr[4], cr4[4];
+                rows4(sv, sr);
+                const T sinB = sr[2], sinMr = sr[3];
                 T x3b;
                 if (VT == ROVMPC_VT_COMPOSE) {
                     // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world with the
                     // cable axes at node n (R @ v of velocity_transform_batch.py:100-101, R composed
                     // from the augmentation angles); only its x component feeds x3
-                    const T st = __shfl(sv, c16, 64), ct = __shfl(cv, c16, 64);
-                    const T sg = __shfl(sv, c16 + 16, 64), cg = __shfl(cv, c16 + 16, 64);
-                    const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
-                    const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
-                    const T *u = &sU[c * US + n * 3];
-                    V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    rows4(cv, cr4);
+                    const V3<T> kt = {ktx, kty, T(0)};
+                    const V3<T> kg = {kgx, kgy, kgz};
+                    V3<T> v = rodrigues_unit<T>({u0, u1, u2}, kg, -sr[1], cr4[1]);
+                    v = rodrigues_unit<T>(v, kt, sr[0], cr4[0]);
                     x3b = (v.x - m3) * i3;
                 } else {
-                    x3b = RV_PL(sX, 0, n + 1, c);
+                    x3b = x3n;
                 }
+                if (n + 1 < nsteps) fetch(n + 1);
                 const T x3m = (x3a + x3b) / T(2);                             // :62 feature midpoint
                 const T s2 = trig.sin((role & 1) ? x3m : x3b);
-                const T sinXb = __shfl(s2, c16, 64), sinXm = __shfl(s2, c16 + 16, 64);
+                T s2r[4];
+                rows4(s2, s2r);
+                const T sinXb = s2r[0], sinXm = s2r[1];
                 const T k1t = (((sinA - sinXa) - s16a) - x3a) * KT;
                 const T k1g = (ga - m15) * i15 - s17a;
                 T thn, gan;
                 if (euler) {
-                    thn = th + k1t * a.h;                                     // main_fun.py:761
-                    gan = ga + k1g * a.h;
+                    thn = th + k1t * kk.h;                                     // main_fun.py:761
+                    gan = ga + k1g * kk.h;
                 } else {
                     const T p16m = hold ? s16a : (s16a + s16b) / T(2);
                     const T p16e = hold ? s16a : s16b, p17e = hold ? s17a : s17b;
@@ -399,7 +462,7 @@ rollout_kernel(const RolloutArgs<T> a) {
                     const T k4t = (((sinE - sinXb) - p16e) - x3b) * KT;
                     const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
                     const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
-                    const T k4g = ((ga + a.h * k3g) - m15) * i15 - p17e;
+                    const T k4g = ((ga + kk.h * k3g) - m15) * i15 - p17e;
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
@@ -407,18 +470,35 @@ rollout_kernel(const RolloutArgs<T> a) {
                 x3a = x3b; sinXa = sinXb; s17a = s17b; sinA = sinB;
                 if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga; }
             }
+        };
+        if (NT > nint) {
+            if (tid < nint) {
+                // the integrating wave is the workgroup's critical path: it outranks the phase-4a
+                // wave it may share a SIMD with
+                __builtin_amdgcn_s_setprio(3);
+                integrate();
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                geometry_a(tid - nint, NT - nint);
+            }
+        } else {
+            integrate();
+            geometry_a(tid, NT);
         }
-    } else if (tid < CK) {
-        const int c = tid;
-        const int nsteps = (a.debug & 1) ? 0 : N;
-        T th = th0, ga = ga0, thm = thm0, gam = gam0;
-        RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
-        const T m14 = sMean[14], i14 = sInv[14], m15 = sMean[15], i15 = sInv[15];
-        const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
-        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
-        const bool euler = a.integrator == ROVMPC_EULER;
-        const T hh = T(0.5) * a.h, h6 = a.h / T(6);
-        {
+    } else {
+        // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
+        const int nint = 64;
+        auto integrate = [&]() {
+            if (tid >= CK) return;
+            const int c = tid;
+            const int nsteps = (a.debug & 1) ? 0 : N;
+            T th = th0, ga = ga0, thm = thm0, gam = gam0;
+            RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
+            const T m14 = sMean[14], i14 = sInv[14], m15 = sMean[15], i15 = sInv[15];
+            const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
+            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+            const bool euler = a.integrator == ROVMPC_EULER;
+            const T hh = T(0.5) * kk.h, h6 = kk.h / T(6);
             // generic path: full 18-slot feature row per stage, bytecode interpreter
             T Vx = V0x, Vy = V0y, Vz = V0z;
             auto store_vslots = [&](int node, T vx, T vy, T vz, T ax, T ay, T az) {
@@ -445,7 +525,7 @@ rollout_kernel(const RolloutArgs<T> a) {
                     const T *u = &sU[c * US + n * 3];
                     V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
                     v = rodrigues_unit<T>(v, kt, st, ct);
-                    store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * a.inv_h, (v.y - Vy) * a.inv_h, (v.z - Vz) * a.inv_h);
+                    store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * kk.inv_h, (v.y - Vy) * kk.inv_h, (v.z - Vz) * kk.inv_h);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
@@ -472,50 +552,47 @@ rollout_kernel(const RolloutArgs<T> a) {
                 stage(th, ga, 0, k1t, k1g);
                 T thn, gan;
                 if (euler) {
-                    thn = th + k1t * a.h;                                     // main_fun.py:761
-                    gan = ga + k1g * a.h;
+                    thn = th + k1t * kk.h;                                     // main_fun.py:761
+                    gan = ga + k1g * kk.h;
                 } else {
                     T k2t, k2g, k3t, k3g, k4t, k4g;
                     stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
                     stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
-                    stage(th + a.h * k3t, ga + a.h * k3g, 2, k4t, k4g);
+                    stage(th + kk.h * k3t, ga + kk.h * k3g, 2, k4t, k4g);
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
                 thm = th; gam = ga; th = thn; ga = gan;
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
             }
+        };
+        if (NT > nint) {
+            if (tid < nint) integrate(); else geometry_a(tid - nint, NT - nint);
+        } else {
+            integrate();
+            geometry_a(tid, NT);
         }
     }
     __syncthreads();
 
-    // ---- phase 4: per-node geometry and cost ----------------------------------------------
+    RV_STAMP(4);
+    // ---- phase 4b: per-node augmented-catenary lowest point and the rest of the cost --------
     const Trig<T> trig4(false);
     for (int i = tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) {
         const int n = i / CK, c = i % CK;
         const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                 rz = RV_PL(sP, 2, n + 1, c) - P0z;
         const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
-        const T *u = &sU[c * US + n * 3];
-        const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
-        const T dH = a.up * rz;                                              // :293
-        const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
-        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, a.up, trig4);
-        const T ls[2] = {l, sh.lp}, ds[2] = {dH, sh.dHp};
-        CatRoot<T> cr[2];
-        solve_catenary_roots<T, 2>(ls, ds, a.L, a.c_lo, a.c_hi, cr);         // :303 and Catenary(A, B')
-        const T Tn = cable_tension<T>(l, cr[0], a.w_per_len);                // :304-305
-        const T zl = P0z + augmented_finish<T>(sh, cr[1], a.L, a.M, a.up);
-        const T eth = th - a.theta_ref, ega = ga - a.gamma_ref;
-        const T e0 = u[0] - a.Uref[0], e1 = u[1] - a.Uref[1], e2 = u[2] - a.Uref[2];
-        const T taut = m_max(T(0), d - a.rhoL);
-        const T flo = m_max(T(0), a.up * (a.z_floor - zl));
-        T cost = a.w_theta * (eth * eth) + a.w_gamma * (ega * ega) + a.w_u * (e0 * e0 + e1 * e1 + e2 * e2)
-               + a.w_T * Tn + a.w_taut * (taut * taut) + a.w_floor * (flo * flo);
-        sC[n * CK + c] = cost;
+        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, kk.up, trig4);
+        const CatRoot<T> cr = solve_catenary_root<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi);   // Catenary(A, B')
+        const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
+        const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
+        const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
+        sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);
     }
     __syncthreads();
 
+    RV_STAMP(5);
     // ---- phase 5: J_k, block arg-min, outputs ---------------------------------------------
     if (tid < 64) {
         const int c = tid;
@@ -556,6 +633,7 @@ rollout_kernel(const RolloutArgs<T> a) {
             }
         }
     }
+    RV_STAMP(6);
     if (!a.result) return;
 
     // ---- arg-min epilogue in the last workgroup to arrive ------------------------------------
@@ -573,6 +651,7 @@ rollout_kernel(const RolloutArgs<T> a) {
         *s_last = ((old + 1ULL) % (unsigned long long)gridDim.x) == 0ULL;
     }
     __syncthreads();
+    RV_STAMP(7);
     if (!*s_last) return;
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -26,7 +26,7 @@ struct rovmpc_handle {
     void *d_consts = nullptr;        // T
     double *d_consts64 = nullptr;    // double (utility kernels)
     void *d_Rtab = nullptr;          // T [N][9]
-    void *d_msc = nullptr;           // T: mean[18], 1/scale[18]
+    void *d_k = nullptr;             // RolloutConsts<T>
     bool has_rtab = false;
     // launch geometry / workspace
     int CK = 0, nblocks = 0, NT = 0;
@@ -35,6 +35,7 @@ struct rovmpc_handle {
     double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
     long long *d_blk_idx = nullptr;
     unsigned long long *d_ticket = nullptr;
+    unsigned long long *d_stamps = nullptr;   // diagnostic library only
     double *h_result = nullptr;      // pinned
     // timing
     std::vector<hipEvent_t> ev;
@@ -172,9 +173,13 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc(&h->d_consts, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
-    CR(hipMalloc(&h->d_msc, 36 * 8));
+    CR(hipMalloc(&h->d_k, sizeof(RolloutConsts<double>)));
     CR(hipMalloc((void **)&h->d_ticket, sizeof(unsigned long long)));
     CR(hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
+#ifdef ROVMPC_STAMPS
+    CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 8 * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_stamps, 0, (size_t)max_blocks * 8 * sizeof(unsigned long long)));
+#endif
 #undef CR
     *out = h;
     return ROVMPC_OK;
@@ -186,11 +191,26 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_msc, h->d_ticket};
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_ticket, h->d_stamps};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+template <typename T> static void fill_consts(const rovmpc_handle *h, RolloutConsts<T> &k) {
+    const rovmpc_config &c = h->cfg;
+    k.h = (T)c.dt; k.vs_h = (T)(c.v_scale * c.dt); k.inv_h = (T)(1.0 / c.dt); k.L = (T)c.L;
+    k.w_per_len = (T)(c.cable_wet_weight / c.L); k.c_lo = (T)c.c_lo; k.c_hi = (T)c.c_hi;
+    k.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
+    k.w_theta = (T)c.w_theta; k.w_gamma = (T)c.w_gamma; k.w_u = (T)c.w_u; k.w_T = (T)c.w_T;
+    k.w_taut = (T)c.w_taut; k.rhoL = (T)(c.rho_taut * c.L); k.w_floor = (T)c.w_floor; k.z_floor = (T)c.z_floor;
+    k.theta_ref = (T)c.theta_ref; k.gamma_ref = (T)c.gamma_ref;
+    for (int i = 0; i < 3; ++i) k.Uref[i] = (T)c.U_ref[i];
+    for (int i = 0; i < 18; ++i) {
+        k.mean[i] = i < h->n_feat ? (T)h->mean[i] : (T)0;
+        k.inv_scale[i] = i < h->n_feat ? (T)(1.0 / h->scale[i]) : (T)1;
+    }
 }
 
 // ---- model ---------------------------------------------------------------------------------
@@ -282,19 +302,14 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
             HIPCHK(h, hipMemcpy(h->d_consts, cf.data(), n_consts * sizeof(float), hipMemcpyHostToDevice));
         }
     }
-    {
-        double msc[36];
-        for (int i = 0; i < 18; ++i) {
-            msc[i] = i < n_features ? mean[i] : 0.0;
-            msc[18 + i] = i < n_features ? 1.0 / scale[i] : 1.0;
-        }
-        if (h->cfg.dtype == ROVMPC_F64) {
-            HIPCHK(h, hipMemcpy(h->d_msc, msc, sizeof(msc), hipMemcpyHostToDevice));
-        } else {
-            float mf[36];
-            for (int i = 0; i < 36; ++i) mf[i] = (float)msc[i];
-            HIPCHK(h, hipMemcpy(h->d_msc, mf, sizeof(mf), hipMemcpyHostToDevice));
-        }
+    if (h->cfg.dtype == ROVMPC_F64) {
+        RolloutConsts<double> k;
+        fill_consts<double>(h, k);
+        HIPCHK(h, hipMemcpy(h->d_k, &k, sizeof(k), hipMemcpyHostToDevice));
+    } else {
+        RolloutConsts<float> k;
+        fill_consts<float>(h, k);
+        HIPCHK(h, hipMemcpy(h->d_k, &k, sizeof(k), hipMemcpyHostToDevice));
     }
     // Fingerprint against the compiled-in rows of saved_models/equations_*.csv
     // (complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3: x15 - x17).
@@ -343,21 +358,15 @@ extern "C" int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R) {
 template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<T> &a, const double *d_state,
                                             const void *d_U, void *d_traj_all) {
     const rovmpc_config &c = h->cfg;
-    a.U = (const T *)d_U; a.state = d_state; a.code_th = h->d_code_th; a.code_ga = h->d_code_ga;
+    a.U = (const T *)d_U; a.state = d_state; a.k = (const RolloutConsts<T> *)h->d_k;
+    a.code_th = h->d_code_th; a.code_ga = h->d_code_ga;
     a.consts = (const T *)h->d_consts; a.Rtab = (const T *)h->d_Rtab;
     a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
     a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
     a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags;
-    a.h = (T)c.dt; a.vs_h = (T)(c.v_scale * c.dt); a.inv_h = (T)(1.0 / c.dt); a.L = (T)c.L;
-    a.w_per_len = (T)(c.cable_wet_weight / c.L); a.c_lo = (T)c.c_lo; a.c_hi = (T)c.c_hi;
-    a.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
-    a.w_theta = (T)c.w_theta; a.w_gamma = (T)c.w_gamma; a.w_u = (T)c.w_u; a.w_T = (T)c.w_T;
-    a.w_taut = (T)c.w_taut; a.rhoL = (T)(c.rho_taut * c.L); a.w_floor = (T)c.w_floor; a.z_floor = (T)c.z_floor;
-    a.theta_ref = (T)c.theta_ref; a.gamma_ref = (T)c.gamma_ref;
-    for (int i = 0; i < 3; ++i) a.Uref[i] = (T)c.U_ref[i];
-    a.msc = (const T *)h->d_msc;
     a.ticket = h->d_ticket;
+    a.stamps = h->d_stamps;
 }
 
 template <typename T, int MODEL, int VT>
@@ -680,3 +689,15 @@ extern "C" int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, cons
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ROVMPC_OK;
 }
+
+#ifdef ROVMPC_STAMPS
+// Diagnostic library only: copy the per-workgroup phase stamps of the last launch to the host.
+extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out, int32_t *nblocks) {
+    if (!h || !out) return ROVMPC_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)h->nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (nblocks) *nblocks = h->nblocks;
+    return ROVMPC_OK;
+}
+#endif

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Print the start/end timeline of the rollout kernel from a rocprofv3 kernel trace (diagnostic)."""
+import csv
+import glob
+import sys
+
+for d in sys.argv[1:]:
+    f = glob.glob(f"{d}/*/*kernel_trace.csv")[0]
+    rows = [r for r in csv.DictReader(open(f)) if "rollout" in r["Kernel_Name"]]
+    rows = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))[-40:]
+    t0 = int(rows[0]["Start_Timestamp"])
+    print(d)
+    for r in rows[:16]:
+        s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        print("  queue", r.get("Queue_Id"), "stream", r.get("Stream_Id"), f"start {s/1e3:9.2f} us  end {e/1e3:9.2f} us  dur {(e-s)/1e3:7.2f} us")
