@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
+    ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows)")
     ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
     args = ap.parse_args()
 
@@ -102,7 +103,13 @@ def main():
     cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
                            candidates_per_block=args.ck, force_interpreter=args.interp, debug_flags=args.debug_flags)
     S = max(1, args.streams) if world == 1 else 1
-    engines = [rovmpc.Engine(cfg) for _ in range(S)]
+    model = rovmpc.default_model()
+    if args.model == "jit-default":
+        model = rovmpc.DynamicsModel(model.mean, model.scale, model.expr_theta + " + 0.0*x0", model.expr_gamma)
+    elif args.model.startswith("rows:"):
+        ct, cg = (int(v) for v in args.model[5:].split(","))
+        model = rovmpc.default_model(ct, cg)
+    engines = [rovmpc.Engine(cfg, model) for _ in range(S)]
     eng = engines[0]
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     pools = []
@@ -188,7 +195,7 @@ def main():
                                    f"(global K={world * args.K}), fused RK4+catenary HIP kernel, {args.dtype}",
                        "N": args.N, "K_per_gpu": args.K, "K_global": world * args.K,
                        "n_shape_pts": cfg.n_shape_pts, "vt_mode": "compose", "dt": cfg.dt,
-                       "model": "compiled-in saved_models rows (13/3)" if not args.interp else "bytecode interpreter",
+                       "model": f"{args.model}: {eng.model_path}",
                        "parallelism": f"candidate-sharded x{world}, 1 all-reduce(min)/step" if world > 1 else "single GPU",
                        "steps_in_flight": S if world == 1 else "rollout(i+1) overlaps all-reduce(i)",
                        "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},

@@ -31,7 +31,7 @@ class Config(C.Structure):
         ("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("N", C.c_int32),
         ("K", C.c_int32), ("n_shape_pts", C.c_int32), ("vt_mode", C.c_int32), ("prev_mode", C.c_int32),
         ("integrator", C.c_int32), ("frame", C.c_int32), ("force_interpreter", C.c_int32),
-        ("candidates_per_block", C.c_int32), ("debug_flags", C.c_int32), ("reserved0", C.c_int32),
+        ("candidates_per_block", C.c_int32), ("debug_flags", C.c_int32), ("jit_off", C.c_int32),
         ("dt", C.c_double), ("v_scale", C.c_double), ("L", C.c_double), ("cable_wet_weight", C.c_double),
         ("c_lo", C.c_double), ("c_hi", C.c_double),
         ("w_theta", C.c_double), ("w_gamma", C.c_double), ("w_u", C.c_double), ("w_T", C.c_double),
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "rovmpc_last_error": (C.c_char_p, [_P]),
     "rovmpc_set_model": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32]),
     "rovmpc_set_rotation_table": (C.c_int, [_P, _P]),
+    "rovmpc_model_path": (C.c_int32, [_P]),
     "rovmpc_step": (C.c_int, [_P, C.POINTER(State), _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "rovmpc_rollout_costs": (C.c_int, [_P, C.POINTER(State), _P, _P, _P]),
     "rovmpc_result_len": (C.c_int32, [_P]),

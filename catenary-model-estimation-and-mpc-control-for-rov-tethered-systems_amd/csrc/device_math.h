@@ -3,9 +3,15 @@
 // Each helper cites the reference statement it restates (paths relative to the reference
 // root).  Everything is templated on the arithmetic type T (double | float).
 #pragma once
+#if !defined(__HIPCC_RTC__)   // hiprtc pre-includes its own HIP runtime declarations
 #include <hip/hip_runtime.h>
+#endif
+#if defined(ROVMPC_JIT_BUILD)
+#include "rovmpc.h"
+#else
 #include <stdint.h>
 #include "../../include/rovmpc.h"
+#endif
 
 namespace rovmpc {
 

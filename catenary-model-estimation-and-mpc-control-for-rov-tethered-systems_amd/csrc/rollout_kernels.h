@@ -25,6 +25,12 @@ namespace rovmpc {
 
 constexpr int MODEL_BUILTIN = 0;   // saved_models/eq_*.txt rows (complexity 13 / 3), compiled in
 constexpr int MODEL_INTERP  = 1;   // any bytecode
+constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compiled with hiprtc at set_model
+
+// Defined by the run-time generated translation unit (MODEL_JIT only): the two expressions
+// over the 18 scaled feature values of one stage.
+template <typename T> __device__ T jit_f_theta(const T *x);
+template <typename T> __device__ T jit_f_gamma(const T *x);
 
 constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
 constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + unit_rel (x,y,z)
@@ -204,8 +210,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 }
 
 template <typename T, int MODEL, int VT>
-__global__ void __launch_bounds__(512)
-rollout_kernel(const RolloutArgs<T> a) {
+RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
     const int N = a.N, CK = a.CK, K = a.K;
@@ -536,6 +541,20 @@ rollout_kernel(const RolloutArgs<T> a) {
                     if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
                     else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
                     else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
+                    if (MODEL == MODEL_JIT) {
+                        // features in registers; loads of slots the expressions never read are dead
+                        T x[18];
+#pragma unroll
+                        for (int s = 0; s < NEXO; ++s) {
+                            if (cfrac2 == 0) x[s] = RV_PL(sX, s, n, c);
+                            else if (cfrac2 == 2) x[s] = RV_PL(sX, s, n + 1, c);
+                            else x[s] = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);   // :62
+                        }
+                        x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
+                        dth = jit_f_theta<T>(x);
+                        dga = jit_f_gamma<T>(x);
+                        return;
+                    }
                     for (int s = 0; s < NEXO; ++s) {
                         T v;
                         if (cfrac2 == 0) v = RV_PL(sX, s, n, c);
@@ -660,6 +679,12 @@ rollout_kernel(const RolloutArgs<T> a) {
     __syncthreads();
     argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, (int)gridDim.x, a.U, N, CK, a.result, a.k_offset,
                        a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4));
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT>(a);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

@@ -7,7 +7,12 @@
 #include <string>
 #include <vector>
 
+#include <hip/hiprtc.h>
+#include <map>
+#include <mutex>
+
 #include "util_kernels.h"
+#include "embedded_sources.inc"
 
 using namespace rovmpc;
 
@@ -19,6 +24,8 @@ struct rovmpc_handle {
     std::string err;
     // model
     bool has_model = false, builtin = false;
+    int model_kind = MODEL_INTERP;   // MODEL_BUILTIN | MODEL_INTERP | MODEL_JIT
+    hipFunction_t jit_fn = nullptr;  // MODEL_JIT: kernel of the run-time specialised module
     int n_feat = 0;
     double mean[ROVMPC_MAX_FEATURES], scale[ROVMPC_MAX_FEATURES];
     int n_th = 0, n_ga = 0, n_consts = 0;
@@ -213,6 +220,116 @@ template <typename T> static void fill_consts(const rovmpc_handle *h, RolloutCon
     }
 }
 
+// ---- run-time specialisation (hiprtc) ---------------------------------------------------------
+// A loaded model that is not the compiled-in one is translated from its bytecode to two C++
+// expressions and the rollout kernel is compiled around them (MODEL_JIT): same kernel source as
+// the library (embedded at build time), features in registers, no interpreter.  Only bytecode
+// that passed validate_code() reaches this point; no source text crosses the C ABI.
+
+static std::string fmt_const(double v) {
+    char b[64];
+    if (std::isnan(v)) return "m_nan<T>()";
+    if (std::isinf(v)) return v > 0 ? "m_inf<T>()" : "(-m_inf<T>())";
+    snprintf(b, sizeof(b), "%.17g", v);
+    std::string t = b;
+    if (t.find_first_of(".eEn") == std::string::npos) t += ".0";
+    return "T(" + t + ")";
+}
+
+static std::string bytecode_to_cxx(const int32_t *code, int n, const double *consts) {
+    std::vector<std::string> st;
+    for (int pc = 0; pc < n; ++pc) {
+        const int op = code[pc] & 0xff, arg = code[pc] >> 8;
+        auto un = [&](const char *f) { std::string a = st.back(); st.back() = std::string(f) + "(" + a + ")"; };
+        auto bin = [&](const char *o) {
+            std::string b = st.back(); st.pop_back();
+            std::string a = st.back(); st.back() = "(" + a + " " + o + " " + b + ")";
+        };
+        switch (op) {
+        case ROVMPC_OP_PUSH_C: st.push_back(fmt_const(consts[arg])); break;
+        case ROVMPC_OP_PUSH_F: st.push_back("x[" + std::to_string(arg) + "]"); break;
+        case ROVMPC_OP_ADD: bin("+"); break;
+        case ROVMPC_OP_SUB: bin("-"); break;
+        case ROVMPC_OP_MUL: bin("*"); break;
+        case ROVMPC_OP_DIV: bin("/"); break;
+        case ROVMPC_OP_POW: { std::string b = st.back(); st.pop_back(); std::string a = st.back();
+                              st.back() = "m_pow(" + a + ", " + b + ")"; break; }
+        case ROVMPC_OP_NEG: un("-"); break;
+        case ROVMPC_OP_SIN: un("m_sin"); break;
+        case ROVMPC_OP_COS: un("m_cos"); break;
+        case ROVMPC_OP_TANH: un("m_tanh"); break;
+        case ROVMPC_OP_ABS: un("m_abs"); break;
+        case ROVMPC_OP_SQUARE: un("rv_sq"); break;
+        case ROVMPC_OP_EXP: un("m_exp"); break;
+        case ROVMPC_OP_LOG: un("m_log"); break;
+        case ROVMPC_OP_SQRT: un("m_sqrt"); break;
+        case ROVMPC_OP_POWI: { const int e = arg >= (1 << 23) ? arg - (1 << 24) : arg;
+                               std::string a = st.back(); st.back() = "rv_powi(" + a + ", " + std::to_string(e) + ")"; break; }
+        case ROVMPC_OP_SAFE_LOG: { std::string a = st.back(); st.back() = "m_log(m_abs(" + a + ") + T(1e-5))"; break; }
+        case ROVMPC_OP_SAFE_SQRT: { std::string a = st.back(); st.back() = "m_sqrt(m_abs(" + a + "))"; break; }
+        default: return "m_nan<T>()";
+        }
+    }
+    return st.empty() ? "m_nan<T>()" : st.back();
+}
+
+struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; };
+static std::mutex g_jit_mu;
+static std::map<std::string, JitModule> g_jit_cache;     // key: device ordinal + generated source
+
+// Returns nullptr and fills `why` when hiprtc cannot produce the kernel.
+static hipFunction_t jit_build(int device, const std::string &src, std::string &why) {
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    const std::string key = std::to_string(device) + "\n" + src;
+    auto it = g_jit_cache.find(key);
+    if (it != g_jit_cache.end()) return it->second.fn;
+    hiprtcProgram prog = nullptr;
+    const char *hdr_src[] = {k_src_rovmpc_h, k_src_device_math_h, k_src_rollout_kernels_h};
+    const char *hdr_name[] = {"rovmpc.h", "device_math.h", "rollout_kernels.h"};
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "rovmpc_jit.hip", 3, hdr_src, hdr_name);
+    if (r != HIPRTC_SUCCESS) { why = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r); return nullptr; }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DROVMPC_JIT_BUILD=1"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        why = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(r) + ": " + log.substr(0, 300);
+        hiprtcDestroyProgram(&prog);
+        return nullptr;
+    }
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    std::vector<char> code(sz);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    JitModule m;
+    hipError_t e = hipModuleLoadData(&m.mod, code.data());
+    if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return nullptr; }
+    e = hipModuleGetFunction(&m.fn, m.mod, "rovmpc_rollout_jit");
+    if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); (void)hipModuleUnload(m.mod); return nullptr; }
+    g_jit_cache[key] = m;
+    return m.fn;
+}
+
+static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
+                              const double *consts) {
+    const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
+    std::string s;
+    s += "#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
+    s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
+    s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
+         "while (ae) { if (ae & 1) r *= b; b *= b; ae >>= 1; } return e < 0 ? T(1) / r : r; }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x) { typedef " + real +
+         " T; return " + bytecode_to_cxx(code_th, n_th, consts) + "; }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x) { typedef " + real +
+         " T; return " + bytecode_to_cxx(code_ga, n_ga, consts) + "; }\n";
+    s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
+         "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
+    return s;
+}
+
 // ---- model ---------------------------------------------------------------------------------
 
 // Host-side evaluation of a bytecode program; used ONLY to fingerprint a loaded model against
@@ -330,13 +447,25 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
         }
     }
     h->builtin = same;
-    if (const char *why = configure_geometry(h, same ? MODEL_BUILTIN : MODEL_INTERP)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
+    h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
+    h->jit_fn = nullptr;
+    h->err.clear();
+    if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features == 18) {
+        std::string why;
+        const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
+        hipFunction_t fn = jit_build(h->cfg.device, src, why);
+        if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; }
+        else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
+    }
+    if (const char *why = configure_geometry(h, h->model_kind)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
     // the ticket counter counts modulo the grid size: restart it with the new geometry
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
     h->has_model = true;
     return ROVMPC_OK;
 }
+
+extern "C" int32_t rovmpc_model_path(const rovmpc_handle *h) { return h ? h->model_kind : -1; }
 
 extern "C" int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R) {
     if (!h) return ROVMPC_ERR_INVALID;
@@ -388,6 +517,12 @@ template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h,
     fill_args<T>(h, a, d_state, d_U, d_traj_all);
     a.result = d_result; a.k_offset = k_offset; a.slots = d_slots; a.rank = rank; a.world = world;
     const int vt = h->cfg.vt_mode;
+    if (h->model_kind == MODEL_JIT) {
+        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt) * sizeof(T);
+        size_t asz = sizeof(a);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(h->jit_fn, h->nblocks, 1, 1, h->NT, 1, 1, (unsigned)lds, s, nullptr, extra);
+    }
     if (h->builtin) {
         if (vt == 0) return launch_one<T, MODEL_BUILTIN, 0>(h, a, s);
         if (vt == 1) return launch_one<T, MODEL_BUILTIN, 1>(h, a, s);

@@ -30,6 +30,7 @@ class MPCConfig:
     force_interpreter: bool = False
     candidates_per_block: int = 0
     debug_flags: int = 0
+    jit: bool = True             # specialise non-default models with hiprtc at set_model
     dt: float = 1.0 / 60.0
     v_scale: float = 1e-3
     L: float = 3.0
@@ -63,6 +64,7 @@ class MPCConfig:
         c.force_interpreter = int(self.force_interpreter)
         c.candidates_per_block = self.candidates_per_block
         c.debug_flags = self.debug_flags
+        c.jit_off = 0 if self.jit else 1
         for k in ("dt", "v_scale", "L", "cable_wet_weight", "c_lo", "c_hi", "w_theta", "w_gamma", "w_u", "w_T",
                   "w_taut", "rho_taut", "w_floor", "z_floor", "theta_ref", "gamma_ref"):
             setattr(c, k, float(getattr(self, k)))
@@ -173,6 +175,13 @@ class Engine:
         self._check(self.lib.rovmpc_set_model(self._h, model.n_features, _ptr(model.mean), _ptr(model.scale),
                                               _ptr(ct), len(ct), _ptr(cg), len(cg), _ptr(cs), len(model.consts)))
         self.model = model
+        note = self.lib.rovmpc_last_error(self._h)
+        self.model_note = note.decode() if note else ""     # e.g. why hiprtc specialisation was not used
+
+    @property
+    def model_path(self) -> str:
+        """'builtin' (compiled-in reference rows), 'interpreter' or 'jit' (hiprtc-specialised)."""
+        return ("builtin", "interpreter", "jit")[int(self.lib.rovmpc_model_path(self._h))]
 
     def set_rotation_table(self, R):
         R = np.ascontiguousarray(R, dtype=np.float64)

@@ -26,7 +26,15 @@
 #ifndef ROVMPC_H
 #define ROVMPC_H
 
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#else   /* hiprtc has no <stdint.h>: the compiler's own type macros give the same typedefs */
+typedef __INT32_TYPE__ int32_t;
+typedef __UINT32_TYPE__ uint32_t;
+typedef __INT64_TYPE__ int64_t;
+typedef __UINT64_TYPE__ uint64_t;
+typedef __UINTPTR_TYPE__ uintptr_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -89,7 +97,7 @@ typedef struct rovmpc_config {
     int32_t force_interpreter;  /* 1: never take the compiled-in default-equation path      */
     int32_t candidates_per_block; /* 0 = auto; else 1..64                                   */
     int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
-    int32_t reserved0;
+    int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
     double L;                   /* cable length [m] (test_cluster.py:22)                    */
@@ -129,6 +137,12 @@ int rovmpc_set_model(rovmpc_handle *h, int32_t n_features,
 /* ROVMPC_VT_TABLE only: R[N][3][3] row-major, rows [exc1 eyc1 ezc1; exc2 ..; exc3 ..]
  * (batch_correct_velocity.py:38-45). */
 int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R);
+
+/* How the loaded model is evaluated inside the rollout kernel: 0 = compiled-in rows of
+ * saved_models/eq_*.txt, 1 = bytecode interpreter, 2 = hiprtc-specialised kernel generated from
+ * the bytecode at rovmpc_set_model (falls back to 1 if hiprtc is unavailable; the reason is then
+ * in rovmpc_last_error). */
+int32_t rovmpc_model_path(const rovmpc_handle *h);
 
 /* ---- the hot path ---------------------------------------------------------------------
  * One MPC step: roll every candidate control sequence U[K][N][3] over the horizon

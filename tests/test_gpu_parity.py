@@ -232,15 +232,47 @@ def test_step_c2_full_size(rv, orc, ck):
     np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
 
 
+@pytest.mark.parametrize("jit", [True, False])
 @pytest.mark.parametrize("ct,cg", [(30, 27), (12, 16), (8, 7), (1, 1), (29, 23)])
-def test_rollout_other_pareto_rows(rv, orc, ct, cg):
-    """Interpreter path on other rows of the reference's Pareto fronts (abs, tanh, square, nested sin)."""
+def test_rollout_other_pareto_rows(rv, orc, ct, cg, jit):
+    """Other rows of the reference's Pareto fronts (abs, tanh, square, nested sin): the hiprtc-
+    specialised kernel and the bytecode interpreter."""
     model = rv.default_model(ct, cg)
-    cfg = rv.MPCConfig(N=12, K=96)
+    cfg = rv.MPCConfig(N=12, K=96, jit=jit)
+    with rv.Engine(cfg, model) as e:
+        assert e.model_path == ("jit" if jit else "interpreter")
     (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg, model)
     np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-12)
     np.testing.assert_allclose(J, Jo, rtol=1e-8)
     assert res.index == int(np.argmin(Jo))
+
+
+@pytest.mark.parametrize("vt_mode,prev_mode,integrator,dtype", [(0, 0, 0, "f64"), (2, 1, 0, "f64"), (1, 0, 1, "f64"), (1, 0, 0, "f32")])
+def test_jit_specialisation_modes(rv, orc, vt_mode, prev_mode, integrator, dtype):
+    """hiprtc-specialised kernel for a model with the generation-2 operator mix, in the other kernel
+    modes, and that the default rows loaded through the JIT route (compiled-in path disabled by a
+    perturbed constant) agree with the compiled-in kernel."""
+    mean, scale = rv.default_model().mean, rv.default_model().scale
+    model = rv.DynamicsModel(mean, scale, "0.05*(sin(x17) - tanh(x3*1.6) - x16) + 0.01*Abs(x11)*x6/(1.0 + x12**2) - 0.002*exp(-x0**2)",
+                             "x15 - x17 + 0.008*(x3 - sin(x15)) + 0.001*x13*cos(x9)")
+    cfg = rv.MPCConfig(N=10, K=80, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator, dtype=dtype)
+    Rtab = rand_rtab(10) if vt_mode == 2 else None
+    with rv.Engine(cfg, model) as e:
+        assert e.model_path == "jit"
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg, model, Rtab=Rtab)
+    tol = 1e-8 if dtype == "f64" else 2e-3
+    np.testing.assert_allclose(traj, trajo, rtol=tol, atol=1e-12 if dtype == "f64" else 1e-5)
+    np.testing.assert_allclose(J, Jo, rtol=tol)
+    if dtype == "f64":
+        assert res.index == int(np.argmin(Jo))
+        m2 = rv.DynamicsModel(mean, scale, rv.default_model().expr_theta + " + 0.0*x0", "x15 - x17")
+        cfg2 = rv.MPCConfig(N=20, K=256, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator)
+        state, U = rv.synthetic_problem(256, 20)
+        with rv.Engine(cfg2, m2) as ej, rv.Engine(cfg2) as eb:
+            if Rtab is not None:
+                R20 = rand_rtab(20); ej.set_rotation_table(R20); eb.set_rotation_table(R20)
+            assert eb.model_path == "builtin"
+            np.testing.assert_allclose(ej.rollout_costs(state, U), eb.rollout_costs(state, U), rtol=1e-11)
 
 
 def test_rollout_c3_fp32(rv, orc):
