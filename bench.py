@@ -74,7 +74,10 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--ck", type=int, default=0, help="candidates per workgroup (0 = auto)")
     ap.add_argument("--pools", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--torch-collective", action="store_true", help="use torch.distributed for the all-reduce instead of the library's own RCCL call")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="single GPU rehearsal of the sharded step: nccl world of 1 with the all-reduce kept")
+    ap.add_argument("--streams", type=int, default=1,
                     help="independent MPC steps in flight on one GPU (one engine handle + HIP stream each); 1 = strictly sequential steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -96,13 +99,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
                            candidates_per_block=args.ck, force_interpreter=args.interp, debug_flags=args.debug_flags)
-    S = max(1, args.streams) if world == 1 else 1
+    S = max(1, args.streams) if (world == 1 and not args.force_collective) else 1
     model = rovmpc.default_model()
     if args.model == "jit-default":
         model = rovmpc.DynamicsModel(model.mean, model.scale, model.expr_theta + " + 0.0*x0", model.expr_gamma)
@@ -121,7 +125,21 @@ def main():
     R = eng.result_len
     stream = torch.cuda.current_stream()
     streams = [stream] if S == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
-    smpc = ShardedMPC(eng, rank=rank, world=world) if world > 1 else None
+    smpc = None
+    collective = None
+    if world > 1 or args.force_collective:
+        if not args.torch_collective:
+            try:        # RCCL called from the library (one C call per step)
+                from rovmpc.sharded import NativeShardedMPC
+                smpc = NativeShardedMPC(eng, rank=rank, world=world)
+                collective = "ncclAllReduce(min) issued by librovmpc"
+            except Exception as exc:                      # noqa: BLE001 -- fall back, never fail the bench
+                if rank == 0:
+                    print(f"[bench] native RCCL path unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                smpc = None
+        if smpc is None:
+            smpc = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective)
+            collective = "torch.distributed all_reduce(MIN) (nccl backend = RCCL)"
     d_res = torch.empty((2 * S, R), dtype=torch.float64, device=dev)
 
     def one_step(i):
@@ -197,7 +215,8 @@ def main():
                        "n_shape_pts": cfg.n_shape_pts, "vt_mode": "compose", "dt": cfg.dt,
                        "model": f"{args.model}: {eng.model_path}",
                        "parallelism": f"candidate-sharded x{world}, 1 all-reduce(min)/step" if world > 1 else "single GPU",
-                       "steps_in_flight": S if world == 1 else "rollout(i+1) overlaps all-reduce(i)",
+                       "steps_in_flight": S if smpc is None else "rollout(i+1) overlaps all-reduce(i)",
+                       "collective": collective,
                        "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
             "best": {"cost": float(last[0]), "index": int(last[1])},
         }

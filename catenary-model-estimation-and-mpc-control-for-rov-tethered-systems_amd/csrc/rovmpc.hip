@@ -8,8 +8,13 @@
 #include <vector>
 
 #include <hip/hiprtc.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "util_kernels.h"
 #include "embedded_sources.inc"
@@ -44,6 +49,24 @@ struct rovmpc_handle {
     unsigned long long *d_ticket = nullptr;
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
     double *h_result = nullptr;      // pinned
+    // native collective (rovmpc_comm_*)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0, comm_flip = 0;
+    hipStream_t comm_stream = nullptr;
+    static constexpr int NSLOT = 4;       // collectives in flight (RCCL's small all-reduce is ~2 rollouts long)
+    long long *d_slots[NSLOT] = {};
+    hipEvent_t ev_rolled[NSLOT] = {}, ev_selected[NSLOT] = {};
+    bool slot_used[NSLOT] = {};
+    // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
+    // host time per call) overlaps the enqueue of the next rollout
+    struct CommJob { int p; double *d_result; };
+    std::thread comm_thread;
+    std::mutex comm_mu;
+    std::condition_variable comm_cv;
+    std::deque<CommJob> comm_q;
+    unsigned long long comm_submitted[NSLOT] = {}, comm_done[NSLOT] = {};
+    bool comm_stop = false;
+    std::string comm_err;
     // timing
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -192,8 +215,11 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     return ROVMPC_OK;
 }
 
+extern "C" int rovmpc_comm_destroy(rovmpc_handle *h);
+
 extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     if (!h) return;
+    (void)rovmpc_comm_destroy(h);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
@@ -836,3 +862,195 @@ extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out
     return ROVMPC_OK;
 }
 #endif
+
+// ---- native collective ------------------------------------------------------------------------
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static const char *rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return nullptr;
+    // a bare SONAME first: binds to the copy already in the process (PyTorch bundles one)
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return "librccl.so not found (dlopen)";
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
+        return "librccl.so lacks an expected symbol";
+    g_rccl = a;
+    return nullptr;
+}
+
+#define NCCLCHK(h, call)                                                                               \
+    do {                                                                                               \
+        ncclResult_t _r = (call);                                                                      \
+        if (_r != ncclSuccess) FAIL(h, ROVMPC_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+extern "C" int rovmpc_comm_unique_id(void *id128) {
+    rovmpc_handle *nullh = nullptr;
+    if (!id128) FAIL(nullh, ROVMPC_ERR_INVALID, "rovmpc_comm_unique_id: null argument");
+    if (const char *why = rccl_load()) FAIL(nullh, ROVMPC_ERR_UNSUPPORTED, "%s", why);
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) FAIL(nullh, ROVMPC_ERR_HIP, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+    memcpy(id128, &id, sizeof(id));
+    return ROVMPC_OK;
+}
+
+static void comm_worker(rovmpc_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
+    const size_t R = rovmpc_result_len(h);
+    for (;;) {
+        rovmpc_handle::CommJob job;
+        {
+            std::unique_lock<std::mutex> lk(h->comm_mu);
+            h->comm_cv.wait(lk, [&] { return h->comm_stop || !h->comm_q.empty(); });
+            if (h->comm_q.empty()) return;            // stop requested and nothing left to enqueue
+            job = h->comm_q.front();
+            h->comm_q.pop_front();
+        }
+        const int p = job.p;
+        std::string err;
+        hipError_t e = hipStreamWaitEvent(h->comm_stream, h->ev_rolled[p], 0);
+        if (e != hipSuccess) err = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e);
+        if (err.empty()) {
+            ncclResult_t r = g_rccl.AllReduce(h->d_slots[p], h->d_slots[p], (size_t)h->comm_world * R, ncclInt64, ncclMin,
+                                              h->comm, h->comm_stream);
+            if (r != ncclSuccess) err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
+        }
+        if (err.empty()) {
+            hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, h->comm_stream, (const long long *)h->d_slots[p],
+                               h->comm_world, (int)R, job.d_result);
+            e = hipGetLastError();
+            if (e != hipSuccess) err = std::string("select kernel: ") + hipGetErrorString(e);
+        }
+        e = hipEventRecord(h->ev_selected[p], h->comm_stream);
+        if (e != hipSuccess && err.empty()) err = std::string("hipEventRecord: ") + hipGetErrorString(e);
+        {
+            std::lock_guard<std::mutex> lk(h->comm_mu);
+            if (!err.empty() && h->comm_err.empty()) h->comm_err = err;
+            ++h->comm_done[p];
+        }
+        h->comm_cv.notify_all();
+    }
+}
+
+// Block the calling thread until the worker has ENQUEUED (not executed) every job on slot p.
+static int comm_wait_enqueued(rovmpc_handle *h, int p) {
+    std::unique_lock<std::mutex> lk(h->comm_mu);
+    h->comm_cv.wait(lk, [&] { return h->comm_done[p] == h->comm_submitted[p]; });
+    if (!h->comm_err.empty()) FAIL(h, ROVMPC_ERR_HIP, "collective worker: %s", h->comm_err.c_str());
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t rank, int32_t world) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_comm_init: bad argument");
+    if (h->comm) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_comm_init: communicator already initialised");
+    if (const char *why = rccl_load()) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "%s", why);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
+    h->comm_rank = rank; h->comm_world = world; h->comm_flip = 0;
+    {
+        // a high-priority stream: the collective and the select are short and latency-critical,
+        // and a priority stream gets a hardware queue of its own, so they really run beside the
+        // rollout kernels of the caller's stream (two same-priority streams can share a queue)
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+    }
+    const size_t R = rovmpc_result_len(h);
+    for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
+        HIPCHK(h, hipMalloc((void **)&h->d_slots[i], (size_t)world * R * sizeof(long long)));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_rolled[i], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_selected[i], hipEventDisableTiming));
+        h->slot_used[i] = false;
+        h->comm_submitted[i] = h->comm_done[i] = 0;
+    }
+    h->comm_stop = false;
+    h->comm_err.clear();
+    h->comm_thread = std::thread(comm_worker, h);
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const void *d_U, int64_t k_offset,
+                                            double *d_result, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->comm) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device_allreduce: call rovmpc_comm_init first");
+    if (!d_state || !d_U || !d_result) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device_allreduce: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int p = h->comm_flip;
+    h->comm_flip = (h->comm_flip + 1) % rovmpc_handle::NSLOT;
+    // slot buffer p is free once the select of NSLOT steps ago has read it
+    if (h->slot_used[p]) {
+        int rc = comm_wait_enqueued(h, p);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_selected[p], 0));
+    }
+    h->slot_used[p] = true;
+    int rc = enqueue_step(h, d_state, d_U, nullptr, h->d_result, k_offset, h->d_slots[p], h->comm_rank, h->comm_world, s);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_rolled[p], s));
+    {
+        std::lock_guard<std::mutex> lk(h->comm_mu);
+        h->comm_q.push_back({p, d_result});
+        ++h->comm_submitted[p];
+    }
+    h->comm_cv.notify_all();
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_comm_join(rovmpc_handle *h, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->comm) return ROVMPC_OK;
+    for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
+        if (!h->slot_used[i]) continue;
+        int rc = comm_wait_enqueued(h, i);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_selected[i], 0));
+    }
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->comm) return ROVMPC_OK;
+    (void)hipSetDevice(h->cfg.device);
+    {
+        std::lock_guard<std::mutex> lk(h->comm_mu);
+        h->comm_stop = true;
+    }
+    h->comm_cv.notify_all();
+    if (h->comm_thread.joinable()) h->comm_thread.join();
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+    (void)g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+    for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
+        if (h->d_slots[i]) (void)hipFree(h->d_slots[i]);
+        if (h->ev_rolled[i]) (void)hipEventDestroy(h->ev_rolled[i]);
+        if (h->ev_selected[i]) (void)hipEventDestroy(h->ev_selected[i]);
+        h->d_slots[i] = nullptr; h->ev_rolled[i] = nullptr; h->ev_selected[i] = nullptr;
+    }
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    h->comm_stream = nullptr;
+    return ROVMPC_OK;
+}

@@ -229,6 +229,29 @@ class Engine:
     def select_device(self, d_slots: int, world: int, d_result: int, stream: int = 0):
         self._check(self.lib.rovmpc_select_device(self._h, d_slots, world, d_result, stream))
 
+    # -- native collective (RCCL called from the library) -----------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.rovmpc_comm_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.rovmpc_last_error(None)
+            raise RovmpcError(rc, msg.decode() if msg else "")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        self._check(self.lib.rovmpc_comm_init(self._h, C.create_string_buffer(unique_id, 128), rank, world))
+
+    def step_device_allreduce(self, d_state: int, d_U: int, k_offset: int, d_result: int, stream: int = 0):
+        self._check(self.lib.rovmpc_step_device_allreduce(self._h, d_state, d_U, k_offset, d_result, stream))
+
+    def comm_join(self, stream: int = 0):
+        self._check(self.lib.rovmpc_comm_join(self._h, stream))
+
+    def comm_destroy(self):
+        self._check(self.lib.rovmpc_comm_destroy(self._h))
+
     def timing_enable(self, max_launches: int):
         self._check(self.lib.rovmpc_timing_enable(self._h, max_launches))
 

@@ -64,7 +64,8 @@ class ShardedMPC:
     the local record (float64 tensor of length R with a GLOBAL index in [1])."""
 
     def __init__(self, engine=None, rank: Optional[int] = None, world: Optional[int] = None,
-                 K_total: Optional[int] = None, local_solver: Optional[Callable] = None, group=None):
+                 K_total: Optional[int] = None, local_solver: Optional[Callable] = None, group=None,
+                 force_collective: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -72,6 +73,7 @@ class ShardedMPC:
         self.world = dist.get_world_size(group) if world is None else world
         self.engine = engine
         self.local_solver = local_solver
+        self.force_collective = force_collective      # run the all-reduce even at world == 1 (rehearsal)
         if engine is None and local_solver is None:
             raise ValueError("ShardedMPC needs an Engine (GPU) or a local_solver")
         if engine is not None:
@@ -80,31 +82,41 @@ class ShardedMPC:
             self.k_offset = shard_bounds(self.K_total, self.rank, self.world)[0]
             dev = torch.device("cuda", engine.cfg.device)
             self.R = engine.result_len
-            # double-buffered slots / results so step i's collective can overlap step i+1's rollout
+            # double-buffered slots / results so step i's collective overlaps step i+1's rollout
             self.slots = [torch.empty((self.world, self.R), dtype=torch.int64, device=dev) for _ in range(2)]
             self.results = [torch.empty(self.R, dtype=torch.float64, device=dev) for _ in range(2)]
             self.comm_stream = torch.cuda.Stream(device=dev)
+            self._rolled = [torch.cuda.Event() for _ in range(2)]      # rollout(i) finished writing slots[i%2]
+            self._selected = [torch.cuda.Event() for _ in range(2)]    # select(i) finished reading slots[i%2]
+            self._used = [False, False]
             self._flip = 0
+            self._graphs = {}
 
     # -- GPU path ----------------------------------------------------------------------------
-    def step_device(self, d_state: torch.Tensor, d_U: torch.Tensor) -> torch.Tensor:
-        """Enqueue one sharded step; returns the device tensor that will hold the global
-        record.  The rollout runs on the current stream, the all-reduce and the select on a
-        side stream, so consecutive independent steps overlap compute with the collective."""
+    def _enqueue(self, d_state: torch.Tensor, d_U: torch.Tensor, i: int, cur, comm):
         eng = self.engine
+        eng.step_device_sharded(d_state.data_ptr(), d_U.data_ptr(), self.k_offset, self.rank, self.world,
+                                self.slots[i].data_ptr(), cur.cuda_stream)
+        self._rolled[i].record(cur)
+        comm.wait_event(self._rolled[i])
+        with torch.cuda.stream(comm):
+            if self.world > 1 or self.force_collective:
+                self.dist.all_reduce(self.slots[i], op=self.dist.ReduceOp.MIN, group=self.group)
+            eng.select_device(self.slots[i].data_ptr(), self.world, self.results[i].data_ptr(), comm.cuda_stream)
+        self._selected[i].record(comm)
+
+    def step_device(self, d_state: torch.Tensor, d_U: torch.Tensor) -> torch.Tensor:
+        """Enqueue one sharded step; returns the device tensor that will hold the global record
+        (valid after ``synchronize()`` or on the side stream).  The rollout runs on the current
+        stream, the all-reduce and the select on a side stream: step i's collective overlaps step
+        i+1's rollout; only step i+2 (same slot buffer) waits for select(i)."""
         i = self._flip
         self._flip ^= 1
         cur = torch.cuda.current_stream()
-        # the side stream may still be reading slots[i] from two steps ago
-        cur.wait_stream(self.comm_stream)
-        eng.step_device_sharded(d_state.data_ptr(), d_U.data_ptr(), self.k_offset, self.rank, self.world,
-                                self.slots[i].data_ptr(), cur.cuda_stream)
-        self.comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self.comm_stream):
-            if self.world > 1:
-                self.dist.all_reduce(self.slots[i], op=self.dist.ReduceOp.MIN, group=self.group)
-            eng.select_device(self.slots[i].data_ptr(), self.world, self.results[i].data_ptr(),
-                              self.comm_stream.cuda_stream)
+        if self._used[i]:
+            cur.wait_event(self._selected[i])      # slots[i] / results[i] are free again
+        self._used[i] = True
+        self._enqueue(d_state, d_U, i, cur, self.comm_stream)
         return self.results[i]
 
     def synchronize(self):
@@ -118,3 +130,46 @@ class ShardedMPC:
         if self.world > 1:
             self.dist.all_reduce(slots, op=self.dist.ReduceOp.MIN, group=self.group)
         return select_record(slots)
+
+
+class NativeShardedMPC:
+    """Candidate-sharded step with the collective issued by the library itself: the fused rollout
+    kernel, ONE ``ncclAllReduce(ncclMin, ncclInt64)`` over xGMI and the select kernel are enqueued
+    by a single C call (``rovmpc_step_device_allreduce``), the collective on the handle's side
+    stream so it overlaps the next step's rollout.  ``torch.distributed`` is used once, to hand the
+    128-byte RCCL id from rank 0 to the other ranks."""
+
+    SLOTS = 4          # ROVMPC_COMM_SLOTS: collectives in flight = result buffers in rotation
+
+    def __init__(self, engine, rank: Optional[int] = None, world: Optional[int] = None,
+                 K_total: Optional[int] = None, group=None):
+        import torch.distributed as dist
+        self.engine = engine
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        K_local = engine.cfg.K
+        self.K_total = K_total if K_total is not None else K_local * self.world
+        self.k_offset = shard_bounds(self.K_total, self.rank, self.world)[0]
+        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        engine.comm_init(box[0], self.rank, self.world)
+        dev = torch.device("cuda", engine.cfg.device)
+        self.R = engine.result_len
+        self.results = [torch.empty(self.R, dtype=torch.float64, device=dev) for _ in range(self.SLOTS)]
+        self._flip = 0
+
+    def step_device(self, d_state: torch.Tensor, d_U: torch.Tensor) -> torch.Tensor:
+        i = self._flip
+        self._flip = (self._flip + 1) % self.SLOTS
+        self.engine.step_device_allreduce(d_state.data_ptr(), d_U.data_ptr(), self.k_offset,
+                                          self.results[i].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return self.results[i]
+
+    def synchronize(self):
+        cur = torch.cuda.current_stream()
+        self.engine.comm_join(cur.cuda_stream)
+        cur.synchronize()
+
+    def close(self):
+        self.engine.comm_destroy()

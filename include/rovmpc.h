@@ -179,6 +179,23 @@ int rovmpc_step_device_sharded(rovmpc_handle *h, const double *d_state, const vo
 int rovmpc_select_device(rovmpc_handle *h, const int64_t *d_slots, int32_t world,
                          double *d_result, void *stream);
 
+/* ---- native collective: the sharded step with RCCL called from the library -----------------
+ * librccl is opened with dlopen at rovmpc_comm_init (no link-time dependency).  Rank 0 obtains a
+ * 128-byte id (rovmpc_comm_unique_id), the host distributes it to every rank out of band
+ * (torch.distributed / MPI / a file), every rank calls rovmpc_comm_init on its handle.
+ * rovmpc_step_device_allreduce then enqueues, without synchronising: the fused rollout kernel on
+ * `stream`, ONE ncclAllReduce(ncclMin, ncclInt64, world * result_len) and the select kernel on
+ * the handle's side stream; d_result is valid once rovmpc_comm_join'ed.  ROVMPC_COMM_SLOTS slot
+ * buffers rotate so the collectives of the last steps overlap the next rollouts; the caller
+ * must keep at least that many d_result buffers in rotation. */
+#define ROVMPC_COMM_SLOTS 4
+int rovmpc_comm_unique_id(void *id128);
+int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t rank, int32_t world);
+int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const void *d_U,
+                                 int64_t k_offset, double *d_result, void *stream);
+int rovmpc_comm_join(rovmpc_handle *h, void *stream);   /* make `stream` wait for the side stream */
+int rovmpc_comm_destroy(rovmpc_handle *h);
+
 /* Per-launch timing of the rollout kernel with HIP events on the launch stream. */
 int rovmpc_timing_enable(rovmpc_handle *h, int32_t max_launches);
 int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t *count);

@@ -429,6 +429,31 @@ def test_sharded_mpc_single_rank_nccl(rv):
         dist.destroy_process_group()
 
 
+def test_native_rccl_step_single_rank(rv):
+    """rovmpc_step_device_allreduce end to end on a one-rank RCCL communicator created by the
+    library itself: same record as the plain step, for several pipelined steps."""
+    import torch
+    from rovmpc.sharded import NativeShardedMPC
+    cfg = rv.MPCConfig(N=20, K=2048)
+    dev = torch.device("cuda", 0)
+    with rv.Engine(cfg) as e:
+        batches = [rv.synthetic_problem(cfg.K, cfg.N, seed=40 + i) for i in range(4)]
+        want = [e.step(batches[0][0], U) for _, U in batches]      # one shared state, four candidate batches
+        smpc = NativeShardedMPC(e, rank=0, world=1)
+        d_state = torch.tensor(batches[0][0], device=dev)
+        dU = [torch.tensor(U, device=dev) for _, U in batches]
+        outs = [smpc.step_device(d_state, dU[i]) for i in range(4)]    # four steps in flight (SLOTS = 4)
+        smpc.synchronize()
+        recs = [(i, outs[i].clone()) for i in range(4)]
+        outs = [smpc.step_device(d_state, dU[3 - i]) for i in range(4)]  # and the buffers are reusable
+        smpc.synchronize()
+        recs += [(3 - i, outs[i].clone()) for i in range(4)]
+        for i, rec in recs:
+            r = rec.cpu().numpy()
+            assert r[0] == want[i].cost and int(r[1]) == want[i].index and np.array_equal(r[2:5], want[i].u)
+        smpc.close()
+
+
 def test_mpc_step_surface_and_closed_loop(rv):
     mpc = rv.MPC(N=20, K=512)
     state, _ = rv.synthetic_problem(512, 20)
