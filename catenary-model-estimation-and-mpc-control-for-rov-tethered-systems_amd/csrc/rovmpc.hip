@@ -119,7 +119,11 @@ static int pick_ck(const rovmpc_config *c, int model) {
     // 16 candidates x 4 role lanes fill one wave in the sequential phase of the compiled-in
     // model; shrink only to keep two workgroups per CU inside the 160 KiB of LDS
     int ck = 16;
-    while (ck > 1 && lds_need(c, ck, model) > 64 * 1024) ck /= 2;
+    // large candidate sets: bigger workgroups (up to 64 candidates = four integrating waves, one
+    // per SIMD) keep about one workgroup per CU instead of queueing several rounds of small ones
+    while (ck < 64 && c->K / (ck * 2) >= 256) ck *= 2;
+    const size_t cap = ck > 16 ? 160 * 1024 : 64 * 1024;
+    while (ck > 1 && lds_need(c, ck, model) > cap) ck /= 2;
     return ck;
 }
 
