@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(PKG_DIR, "lib", "librovmpc.so")
 F64, F32 = 0, 1
 VT_NONE, VT_COMPOSE, VT_TABLE = 0, 1, 2
 PREV_INTERP, PREV_HOLD = 0, 1
-RK4, EULER = 0, 1
+RK4, EULER, DOUBLE_EULER, TRAPEZOID = 0, 1, 2, 3
 ENU, NED = 0, 1
 STATE_LEN = 16
 

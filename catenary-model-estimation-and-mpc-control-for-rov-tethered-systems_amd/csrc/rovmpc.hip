@@ -720,7 +720,7 @@ extern "C" int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *t
                              int32_t integrator, double *theta_out, double *gamma_out) {
     if (!h) return ROVMPC_ERR_INVALID;
     if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
-    if (T < 1 || !Xs || !time || (integrator != ROVMPC_RK4 && integrator != ROVMPC_EULER))
+    if (T < 1 || !Xs || !time || integrator < ROVMPC_RK4 || integrator > ROVMPC_TRAPEZOID)
         FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_replay: bad argument");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     DevBuf dX, dT, dIt, dIg, dOt, dOg;
@@ -730,6 +730,23 @@ extern "C" int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *t
     HIPCHK(h, dIg.alloc((size_t)T * sizeof(double)));
     HIPCHK(h, dOt.alloc((size_t)T * sizeof(double)));
     HIPCHK(h, dOg.alloc((size_t)T * sizeof(double)));
+    if (integrator >= ROVMPC_DOUBLE_EULER) {
+        // second-derivative models: predict every row, then integrate twice
+        const int bs = 256;
+        for (int which = 0; which < 2; ++which) {
+            hipLaunchKernelGGL(predict_kernel, dim3(grid_for(T, bs)), dim3(bs), ROVMPC_MAX_STACK * bs * sizeof(double), h->stream,
+                               dX.as<double>(), (long long)T, h->n_feat, which == 0 ? h->d_code_th : h->d_code_ga,
+                               which == 0 ? h->n_th : h->n_ga, h->d_consts64, which == 0 ? dIt.as<double>() : dIg.as<double>());
+            HIPCHK(h, hipGetLastError());
+        }
+        hipLaunchKernelGGL(replay_second_order_kernel, dim3(1), dim3(64), 0, h->stream, dIt.as<double>(), dIg.as<double>(),
+                           dT.as<double>(), (long long)T, theta0, gamma0, integrator, dOt.as<double>(), dOg.as<double>());
+        HIPCHK(h, hipGetLastError());
+        if (theta_out) HIPCHK(h, hipMemcpyAsync(theta_out, dOt.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (gamma_out) HIPCHK(h, hipMemcpyAsync(gamma_out, dOg.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return ROVMPC_OK;
+    }
     if (T > 1) {
         const int bs = 128;
         const size_t lds = (size_t)(h->n_feat + ROVMPC_MAX_STACK) * bs * sizeof(double);

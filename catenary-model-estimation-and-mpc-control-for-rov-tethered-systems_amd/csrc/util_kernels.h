@@ -50,6 +50,33 @@ replay_increments_kernel(const double *__restrict__ Xs, const double *__restrict
     if (i0 < T) { inc_th[i0] = it; inc_ga[i0] = ig; }
 }
 
+// Second-order replays: dd[i] = model.predict(X[i]) for every row (stored in inc_*), then
+//   double Euler (test_cluster.py:110-129):  w[i] = w[i-1] + dd[i-1] dt_i ; y[i] = y[i-1] + w[i-1] dt_i
+//   trapezoid   (dd_cluster.py:221-226):     w[i] = w[i-1] + (dd[i-1] + dd[i])/2 dt_i ; y[i] = y[i-1] + dt_i w[i]
+// both from w[0] = 0, in the reference's sequential order; two lanes, one per series.
+__global__ void __launch_bounds__(64)
+replay_second_order_kernel(const double *dd_th, const double *dd_ga, const double *time, long long T, double th0,
+                           double ga0, int integrator, double *th_out, double *ga_out) {
+    const int w = threadIdx.x;
+    if (w > 1) return;
+    const double *dd = w == 0 ? dd_th : dd_ga;
+    double *out = w == 0 ? th_out : ga_out;
+    if (!out) return;
+    double y = w == 0 ? th0 : ga0, v = 0.0;
+    out[0] = y;
+    for (long long i = 1; i < T; ++i) {
+        const double dt = time[i] - time[i - 1];
+        if (integrator == ROVMPC_DOUBLE_EULER) {
+            y = y + v * dt;
+            v = v + dd[i - 1] * dt;
+        } else {
+            v = v + (dd[i - 1] + dd[i]) / 2 * dt;
+            y = y + dt * v;
+        }
+        out[i] = y;
+    }
+}
+
 // y[i] = y[i-1] + inc[i] in the reference's (sequential) order; two lanes, one per series.
 __global__ void __launch_bounds__(64)
 replay_cumsum_kernel(const double *inc_th, const double *inc_ga, long long T, double th0, double ga0,

@@ -4,6 +4,10 @@
     integrate_theta_gamma(model_theta, model_gamma, X,
                           time_array, theta_0, gamma_0)   main_fun.py:735-764
 
+    integrate_second_order(model_ddtheta, model_ddgamma, X, time,
+                           theta_0, gamma_0, method)      test_cluster.py:110-129 ("double_euler"),
+                                                          dd_cluster.py:221-226 ("trapezoid")
+
 ``model`` objects are ``SymbolicRegressor`` instances (below) -- the stand-in for the
 reference's ``PySRRegressor`` restricted to one equation row: ``.predict(X(n,F)) -> (n,)``.
 """
@@ -57,3 +61,15 @@ def integrate_theta_gamma(model_theta: SymbolicRegressor, model_gamma: SymbolicR
 def rk4_theta_gamma(model_theta: SymbolicRegressor, model_gamma: SymbolicRegressor, X, time_array, theta_0, gamma_0):
     """Both RK4 replays of simulate_rk4_theta_gamma.py:74-75 in one launch."""
     return model_theta._pair(model_gamma).replay(X, time_array, theta_0, gamma_0, _lib.RK4)
+
+
+def integrate_second_order(model_ddtheta: SymbolicRegressor, model_ddgamma: SymbolicRegressor, X, time_array,
+                           theta_0, gamma_0, method: str = "double_euler"):
+    """Second-derivative models (theta'', gamma''), integrated twice from zero angular velocity the
+    way the reference's second-order evaluation scripts do: ``"double_euler"`` =
+    test_cluster.py:110-129, ``"trapezoid"`` = cumulative_trapezoid + cumsum of
+    dd_cluster.py:221-226."""
+    modes = {"double_euler": _lib.DOUBLE_EULER, "trapezoid": _lib.TRAPEZOID}
+    if method not in modes:
+        raise ValueError("method must be 'double_euler' or 'trapezoid'")
+    return model_ddtheta._pair(model_ddgamma).replay(X, time_array, theta_0, gamma_0, modes[method])

@@ -58,6 +58,8 @@ extern "C" {
 
 #define ROVMPC_RK4   0        /* simulate_rk4_theta_gamma.py:52-68                         */
 #define ROVMPC_EULER 1        /* main_fun.py:735-764                                       */
+#define ROVMPC_DOUBLE_EULER 2 /* replay only: second-derivative models, test_cluster.py:110-129 */
+#define ROVMPC_TRAPEZOID 3    /* replay only: cumulative_trapezoid + cumsum, dd_cluster.py:221-226 */
 
 #define ROVMPC_ENU 0
 #define ROVMPC_NED 1
@@ -208,7 +210,10 @@ int rovmpc_predict(rovmpc_handle *h, const double *Xs, int64_t n, int32_t which,
 
 /* rk4_integration(model, x_input, time, y0) (simulate_rk4_theta_gamma.py:52-68) when
  * integrator == ROVMPC_RK4, integrate_theta_gamma (main_fun.py:735-764) when ROVMPC_EULER;
- * both expressions in one call, either output may be NULL.  Xs[T][F] scaled rows. */
+ * both expressions in one call, either output may be NULL.  Xs[T][F] scaled rows.
+ * ROVMPC_DOUBLE_EULER / ROVMPC_TRAPEZOID treat the expressions as second derivatives
+ * (theta'', gamma'') and integrate twice from zero angular velocity, as the reference's
+ * second-order evaluation scripts do (test_cluster.py:110-129, dd_cluster.py:221-226). */
 int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *time, int64_t T,
                   double theta0, double gamma0, int32_t integrator,
                   double *theta_out, double *gamma_out);

@@ -141,6 +141,37 @@ def euler_replay(predict_theta, predict_gamma, X, time_array, theta_0, gamma_0):
     return th, ga
 
 
+def double_euler_replay(dd_theta, dd_gamma, time, theta_0, gamma_0):
+    """test_cluster.py:110-129: angular velocities from zero by Euler, then angles by Euler."""
+    dd = [np.asarray(dd_theta, float), np.asarray(dd_gamma, float)]
+    time = np.asarray(time, float)
+    out = []
+    for d, y0 in zip(dd, (theta_0, gamma_0)):
+        dot = np.zeros_like(d)
+        for i in range(1, len(time)):
+            dt = time[i] - time[i - 1]
+            dot[i] = dot[i - 1] + d[i - 1] * dt
+        est = np.zeros_like(d)
+        est[0] = y0
+        for i in range(1, len(time)):
+            dt = time[i] - time[i - 1]
+            est[i] = est[i - 1] + dot[i - 1] * dt
+        out.append(est)
+    return out[0], out[1]
+
+
+def trapezoid_replay(dd_theta, dd_gamma, time, theta_0, gamma_0):
+    """dd_cluster.py:221-230: cumulative_trapezoid(initial=0) then theta0 + cumsum(diff(time) * dot[1:])."""
+    from scipy.integrate import cumulative_trapezoid
+    time = np.asarray(time, float)
+    out = []
+    for d, y0 in zip((dd_theta, dd_gamma), (theta_0, gamma_0)):
+        dot = cumulative_trapezoid(np.asarray(d, float), time, initial=0)
+        est = y0 + np.cumsum(np.diff(time) * dot[1:])
+        out.append(np.insert(est, 0, y0))
+    return out[0], out[1]
+
+
 # --------------------------------------------------------------------------------------
 # A5 -- catenary parameter and tension
 # --------------------------------------------------------------------------------------

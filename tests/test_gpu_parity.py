@@ -166,6 +166,23 @@ def test_replay_integrators(rv, golden_dir, equations):
     np.testing.assert_allclose(mt.predict(g["Xs"]), mt._pair(mt).predict(g["Xs"], 0))
 
 
+def test_second_order_replays(rv, orc, golden_dir, equations):
+    """Double-Euler (test_cluster.py:110-129) and trapezoid+cumsum (dd_cluster.py:221-226) replays of
+    second-derivative models, against the oracle's statement-by-statement restatement."""
+    g = np.load(os.path.join(golden_dir, "kat_replay.npz"))
+    et = equations["dtheta_dt"]["rows"][-1]["sympy_format"]; eg = equations["dgamma_dt"]["rows"][-1]["sympy_format"]
+    mt, mg = rv.SymbolicRegressor(et), rv.SymbolicRegressor(eg)
+    ddt = orc.SymbolicModel(et).predict(g["Xs"]); ddg = orc.SymbolicModel(eg).predict(g["Xs"])
+    th, ga = rv.integrate_second_order(mt, mg, g["Xs"], g["time"], -0.03, -0.05, "double_euler")
+    wt, wg = orc.double_euler_replay(ddt, ddg, g["time"], -0.03, -0.05)
+    np.testing.assert_allclose(th, wt, rtol=1e-11, atol=1e-14); np.testing.assert_allclose(ga, wg, rtol=1e-11, atol=1e-14)
+    th, ga = rv.integrate_second_order(mt, mg, g["Xs"], g["time"], -0.03, -0.05, "trapezoid")
+    wt, wg = orc.trapezoid_replay(ddt, ddg, g["time"], -0.03, -0.05)
+    np.testing.assert_allclose(th, wt, rtol=1e-11, atol=1e-14); np.testing.assert_allclose(ga, wg, rtol=1e-11, atol=1e-14)
+    with pytest.raises(ValueError):
+        rv.integrate_second_order(mt, mg, g["Xs"], g["time"], 0.0, 0.0, "simpson")
+
+
 def test_velocity_transform(rv):
     rng = np.random.default_rng(3)
     R = rand_rtab(50); v = rng.standard_normal((50, 3))

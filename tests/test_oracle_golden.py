@@ -207,3 +207,16 @@ def test_scalar_and_vector_flavours_agree(oracle_model, vt_mode, prev_mode, inte
     np.testing.assert_allclose(auxv["z_low"], auxs["z_low"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(Jv, Js, rtol=1e-10)
     assert int(np.argmin(Jv)) == int(np.argmin(Js))
+
+
+def test_second_order_replays_are_consistent():
+    """Constant second derivative a: double Euler gives y0 + a dt^2 i(i-1)/2, trapezoid gives
+    y0 + a dt^2 i(i+1)/2 (the reference's cumsum uses the END-of-step velocity)."""
+    t = np.arange(11) * 0.1
+    a = np.full(11, 2.0)
+    th, ga = orc.double_euler_replay(a, -a, t, 1.0, -1.0)
+    i = np.arange(11)
+    np.testing.assert_allclose(th, 1.0 + 2.0 * 0.01 * i * (i - 1) / 2, rtol=1e-12)
+    np.testing.assert_allclose(ga, -th, rtol=1e-12)
+    th, _ = orc.trapezoid_replay(a, a, t, 1.0, 1.0)
+    np.testing.assert_allclose(th, 1.0 + 2.0 * 0.01 * i * (i + 1) / 2, rtol=1e-12)
