@@ -12,7 +12,8 @@ from .model import (DynamicsModel, default_model, load_model_dir, read_equation_
                     chosen_complexity_from_txt, FEATURE_NAMES_GEN1)
 from .engine import Engine, MPCConfig, MPCState, StepResult, default_engine, state_array
 from .geometry import (rodrigues_rotation, transform_catenary, transform_catenary_batch, solve_catenary,
-                       cable_tension, Catenary, lowest_point, rotation_axes, velocity_transform)
+                       cable_tension, Catenary, lowest_point, rotation_axes, velocity_transform,
+                       kabsch_velocity_transform, compute_rotation_kabsch)
 from .integrate import (SymbolicRegressor, rk4_integration, integrate_theta_gamma, rk4_theta_gamma,
                         integrate_second_order)
 from .features import extract_features, extract_features_arrays

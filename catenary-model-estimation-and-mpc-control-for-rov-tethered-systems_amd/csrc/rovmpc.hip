@@ -884,6 +884,28 @@ extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out
 }
 #endif
 
+extern "C" int rovmpc_kabsch_velocity_transform(rovmpc_handle *h, const double *P, const double *Q, const double *v, int64_t T,
+                                                int32_t M, int32_t batch_gates, double *v_out, double *R_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (T < 0 || M < 1 || M > 4096 || (T > 0 && (!P || !Q || !v || !v_out)))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_kabsch_velocity_transform: bad argument");
+    if (T == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dP, dQ, dv, dout, dR;
+    UPLOAD(h, dP, P, (size_t)T * M * 3 * sizeof(double));
+    UPLOAD(h, dQ, Q, (size_t)T * M * 3 * sizeof(double));
+    UPLOAD(h, dv, v, (size_t)T * 3 * sizeof(double));
+    HIPCHK(h, dout.alloc((size_t)T * 3 * sizeof(double)));
+    HIPCHK(h, dR.alloc((size_t)T * 9 * sizeof(double)));
+    hipLaunchKernelGGL(kabsch_kernel, dim3(grid_for(T, 128)), dim3(128), 0, h->stream, dP.as<double>(), dQ.as<double>(),
+                       dv.as<double>(), (long long)T, M, batch_gates, dout.as<double>(), R_out ? dR.as<double>() : nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(v_out, dout.p, (size_t)T * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (R_out) HIPCHK(h, hipMemcpyAsync(R_out, dR.p, (size_t)T * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 // ---- native collective ------------------------------------------------------------------------
 
 struct RcclApi {

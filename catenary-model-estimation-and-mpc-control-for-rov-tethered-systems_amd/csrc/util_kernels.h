@@ -230,4 +230,82 @@ velocity_transform_kernel(const double *R, const double *v, long long n, double 
     out[3 * i + 2] = r[6] * u[0] + r[7] * u[1] + r[8] * u[2];
 }
 
+// compute_rotation_kabsch (velocity_transform_batch.py:8-19) + the per-frame gates of :75-101,
+// one lane per frame.  H = Pc^T Qc = U S V^T; R = V U^T with the reflection fix.  A proper
+// rotation that maps u1 -> v1 and u2 -> v2 is unique, so R needs only the two dominant singular
+// pairs: R = [v1 v2 v1xv2] [u1 u2 u1xu2]^T (this is what numpy's V^T-row flip produces, for any
+// sign convention of the SVD, including the nearly planar marker sets a cable gives).
+// The pairs come from one-sided Jacobi on the 3x3 H (column rotations until orthogonal).
+__global__ void __launch_bounds__(128)
+kabsch_kernel(const double *__restrict__ P, const double *__restrict__ Q, const double *__restrict__ v, long long T, int M,
+              int batch_gates, double *v_out, double *R_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const double nan = m_nan<double>();
+    const double *p = P + (size_t)t * M * 3, *q = Q + (size_t)t * M * 3;
+    double cp[3] = {0, 0, 0}, cq[3] = {0, 0, 0}, d2 = 0;
+    bool finite = true;
+    for (int i = 0; i < M; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const double x = p[3 * i + a], y = q[3 * i + a];
+            finite = finite && m_finite(x) && m_finite(y);
+            cp[a] += x; cq[a] += y;
+            d2 += (x - y) * (x - y);
+        }
+    bool ok = finite && M >= 3 && !(batch_gates && m_sqrt(d2) < 1e-6);
+    double R[9];
+    if (ok) {
+        for (int a = 0; a < 3; ++a) { cp[a] /= M; cq[a] /= M; }
+        double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};           // H[a][b] = sum_i Pc[i][a] Qc[i][b]
+        for (int i = 0; i < M; ++i)
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) A[a][b] += (p[3 * i + a] - cp[a]) * (q[3 * i + b] - cq[b]);
+        double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            bool rotated = false;
+#pragma unroll
+            for (int pair = 0; pair < 3; ++pair) {
+                const int c0 = pair == 2 ? 1 : 0, c1 = pair == 0 ? 1 : 2;
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < 3; ++r) { al += A[r][c0] * A[r][c0]; be += A[r][c1] * A[r][c1]; ga += A[r][c0] * A[r][c1]; }
+                if (m_abs(ga) > 1e-17 * m_sqrt(al * be) && ga != 0.0) {
+                    const double zeta = (be - al) / (2 * ga);
+                    const double tt = (zeta >= 0 ? 1.0 : -1.0) / (m_abs(zeta) + m_sqrt(1 + zeta * zeta));
+                    const double c = 1.0 / m_sqrt(1 + tt * tt), s = c * tt;
+                    for (int r = 0; r < 3; ++r) {
+                        const double a0 = A[r][c0], a1 = A[r][c1];
+                        A[r][c0] = c * a0 - s * a1; A[r][c1] = s * a0 + c * a1;
+                        const double v0 = V[r][c0], v1 = V[r][c1];
+                        V[r][c0] = c * v0 - s * v1; V[r][c1] = s * v0 + c * v1;
+                    }
+                    rotated = rotated || m_abs(ga) > 1e-15 * m_sqrt(al * be);
+                }
+            }
+            if (!rotated) break;
+        }
+        // columns of A are sigma_j u_j, columns of V are v_j; take the two largest sigma
+        double sg[3];
+        for (int j = 0; j < 3; ++j) sg[j] = m_sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+        int j0 = 0;
+        if (sg[1] > sg[j0]) j0 = 1;
+        if (sg[2] > sg[j0]) j0 = 2;
+        int j1 = j0 == 0 ? 1 : 0;
+        for (int j = 0; j < 3; ++j) if (j != j0 && sg[j] > sg[j1]) j1 = j;
+        V3<double> u1 = {A[0][j0] / sg[j0], A[1][j0] / sg[j0], A[2][j0] / sg[j0]};
+        V3<double> u2 = {A[0][j1] / sg[j1], A[1][j1] / sg[j1], A[2][j1] / sg[j1]};
+        const V3<double> v1 = {V[0][j0], V[1][j0], V[2][j0]}, v2 = {V[0][j1], V[1][j1], V[2][j1]};
+        const V3<double> u3 = cross3(u1, u2), v3 = cross3(v1, v2);
+        // R = V U^T = sum_j v_j u_j^T  (velocity_transform_batch.py:15)
+        const double uu[3][3] = {{u1.x, u1.y, u1.z}, {u2.x, u2.y, u2.z}, {u3.x, u3.y, u3.z}};
+        const double vv[3][3] = {{v1.x, v1.y, v1.z}, {v2.x, v2.y, v2.z}, {v3.x, v3.y, v3.z}};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) R[3 * a + b] = vv[0][a] * uu[0][b] + vv[1][a] * uu[1][b] + vv[2][a] * uu[2][b];
+        for (int a = 0; a < 9; ++a) ok = ok && m_finite(R[a]);
+    }
+    const double *w = v + 3 * t;
+    for (int a = 0; a < 3; ++a)
+        v_out[3 * t + a] = ok ? R[3 * a] * w[0] + R[3 * a + 1] * w[1] + R[3 * a + 2] * w[2] : nan;   // :100-101
+    if (R_out) for (int a = 0; a < 9; ++a) R_out[9 * t + a] = ok ? R[a] : nan;
+}
+
 }  // namespace rovmpc

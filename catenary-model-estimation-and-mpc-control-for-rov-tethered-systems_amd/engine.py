@@ -321,6 +321,18 @@ class Engine:
         return out
 
 
+    def kabsch_velocity_transform(self, P, Q, v, batch_gates: bool = True):
+        P = np.ascontiguousarray(P, np.float64); Q = np.ascontiguousarray(Q, np.float64)
+        v = np.ascontiguousarray(v, np.float64).reshape(-1, 3)
+        if P.ndim != 3 or P.shape[2] != 3 or Q.shape != P.shape or v.shape[0] != P.shape[0]:
+            raise ValueError("P, Q must be (T, M, 3) and v (T, 3)")
+        T, M = P.shape[0], P.shape[1]
+        out = np.empty((T, 3)); R = np.empty((T, 3, 3))
+        self._check(self.lib.rovmpc_kabsch_velocity_transform(self._h, _ptr(P), _ptr(Q), _ptr(v), T, M, int(batch_gates),
+                                                              _ptr(out), _ptr(R)))
+        return out, R
+
+
 _default_engine: Optional[Engine] = None
 
 

@@ -6,6 +6,7 @@
     Catenary(length=3., reference_frame='ENU')(a, b)                 catenary.py:10,25-29
     lowest_point(points)                                             fully_augmented_catenary.py:21-22
     velocity_transform(R, v)                                         velocity_transform_batch.py:100-101
+    compute_rotation_kabsch(P, Q), kabsch_velocity_transform(...)    velocity_transform_batch.py:8-19, 71-107
 
 Same names, argument order and return shapes as the reference; array arguments may also be
 batched (leading dimension) where the reference loops row by row.
@@ -149,3 +150,18 @@ def velocity_transform(R, v_world):
     """rob_cor_speed = R @ rob_speed per row (velocity_transform_batch.py:100-101)."""
     v = np.asarray(v_world, float)
     return default_engine().velocity_transform(R, v.reshape(-1, 3)).reshape(v.shape)
+
+
+def kabsch_velocity_transform(original_points, corrected_points, rob_speed, batch_gates: bool = True):
+    """``rob_cor_speed`` for T frames: Kabsch rotation of the cable markers (T, M, 3) original ->
+    corrected, applied to ``rob_speed`` (T, 3).  ``batch_gates=True`` follows
+    velocity_transform_batch.py:75-101 (NaN rows for non-finite markers, fewer than 3 markers or
+    |P - Q| < 1e-6), ``False`` follows velocity_transform.py:60-80.  Returns (v (T,3), R (T,3,3))."""
+    return default_engine().kabsch_velocity_transform(original_points, corrected_points, rob_speed, batch_gates)
+
+
+def compute_rotation_kabsch(P, Q):
+    """velocity_transform_batch.py:8-19 for one frame: (N,3) original and corrected points -> R (3,3)."""
+    P = np.asarray(P, float); Q = np.asarray(Q, float)
+    _, R = default_engine().kabsch_velocity_transform(P[None], Q[None], np.zeros((1, 3)), batch_gates=False)
+    return R[0]

@@ -246,6 +246,14 @@ int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B
 int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, const double *v,
                               int64_t n, double *out);
 
+/* velocity_transform_batch.py:8-19,71-107 (batch_gates = 1) / velocity_transform.py:42-80
+ * (batch_gates = 0) for T frames of M cable markers: R = Kabsch rotation of the centred marker
+ * sets P[T][M][3] -> Q[T][M][3] (3x3 SVD with the reflection fix), v_out = R @ v.
+ * Frames with a non-finite marker, M < 3 or (batch_gates) |P - Q|_F < 1e-6 yield NaN rows,
+ * as the reference writes.  R_out[T][9] may be NULL. */
+int rovmpc_kabsch_velocity_transform(rovmpc_handle *h, const double *P, const double *Q, const double *v,
+                                     int64_t T, int32_t M, int32_t batch_gates, double *v_out, double *R_out);
+
 #ifdef __cplusplus
 }
 #endif

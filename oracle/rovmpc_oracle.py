@@ -369,6 +369,39 @@ def velocity_transform_table(R, v_world):
     return np.einsum("tij,tj->ti", R, v_world)
 
 
+def compute_rotation_kabsch(P, Q):
+    """velocity_transform_batch.py:8-19 (== velocity_transform.py:42-54), statement by statement."""
+    centroid_P = P.mean(axis=0)
+    centroid_Q = Q.mean(axis=0)
+    P_centered = P - centroid_P
+    Q_centered = Q - centroid_Q
+    H = P_centered.T @ Q_centered
+    U, _, Vt = np.linalg.svd(H)
+    R = Vt.T @ U.T
+    if np.linalg.det(R) < 0:
+        Vt[-1, :] *= -1
+        R = Vt.T @ U.T
+    return R
+
+
+def kabsch_velocity_transform(original_points, corrected_points, rob_speed, batch_gates=True):
+    """Per-frame loop of velocity_transform_batch.py:71-107 (batch_gates) / velocity_transform.py:60-80."""
+    out, Rs = [], []
+    nan3 = [np.nan] * 3
+    for t in range(len(rob_speed)):
+        P = original_points[t]; Q = corrected_points[t]
+        bad = not (np.isfinite(P).all() and np.isfinite(Q).all())
+        bad = bad or P.shape[0] < 3
+        bad = bad or (batch_gates and np.linalg.norm(P - Q) < 1e-6)
+        if bad:
+            out.append(nan3); Rs.append(np.full((3, 3), np.nan)); continue
+        R = compute_rotation_kabsch(P, Q)
+        if batch_gates and (not np.allclose(R.T @ R, np.eye(3), atol=1e-2) or not np.isclose(np.linalg.det(R), 1.0, atol=1e-2)):
+            out.append(nan3); Rs.append(np.full((3, 3), np.nan)); continue
+        out.append(R @ rob_speed[t]); Rs.append(R)
+    return np.array(out), np.array(Rs)
+
+
 def velocity_transform_compose(v_world, rel, theta, gamma):
     """Build-defined world->catenary-frame rotation from (theta, gamma):
     v_cat = R_theta(+theta) R_gamma(-gamma) v, the inverse of the augmentation of

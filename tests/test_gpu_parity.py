@@ -183,6 +183,32 @@ def test_second_order_replays(rv, orc, golden_dir, equations):
         rv.integrate_second_order(mt, mg, g["Xs"], g["time"], 0.0, 0.0, "simpson")
 
 
+def test_kabsch_velocity_transform(rv, orc, golden_dir):
+    """Batched Kabsch (3x3 SVD + reflection fix) against the reference's own function on cable-like
+    (nearly planar), exactly planar and generic marker sets, plus the per-frame gates."""
+    g = np.load(os.path.join(golden_dir, "kat_kabsch.npz"))
+    v, R = rv.kabsch_velocity_transform(g["P"], g["Q"], g["v"])
+    np.testing.assert_allclose(R, g["R"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(v, g["v_out"], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(rv.compute_rotation_kabsch(g["P"][3], g["Q"][3]), g["R"][3], atol=1e-10)
+    # gates: NaN marker, no motion (batch variant only), reflection case
+    P = g["P"][:4].copy(); Q = g["Q"][:4].copy(); vv = g["v"][:4].copy()
+    P[1, 2, 0] = np.nan
+    Q[2] = P[2]
+    Q[3] = P[3] * np.array([1.0, 1.0, -1.0])          # mirrored set: best PROPER rotation, det = +1
+    got, Rg = rv.kabsch_velocity_transform(P, Q, vv, batch_gates=True)
+    want, Rw = orc.kabsch_velocity_transform(P, Q, vv, batch_gates=True)
+    assert np.isnan(got[1]).all() and np.isnan(got[2]).all() and np.isnan(want[2]).all()
+    np.testing.assert_allclose(got[[0, 3]], want[[0, 3]], rtol=1e-9, atol=1e-8)
+    assert np.linalg.det(Rg[3]) == pytest.approx(1.0, abs=1e-10)
+    got2, _ = rv.kabsch_velocity_transform(P, Q, vv, batch_gates=False)
+    want2, _ = orc.kabsch_velocity_transform(P, Q, vv, batch_gates=False)
+    assert np.isnan(got2[1]).all() and np.isfinite(got2[2]).all()
+    np.testing.assert_allclose(got2[[0, 2, 3]], want2[[0, 2, 3]], rtol=1e-9, atol=1e-8)
+    with pytest.raises(ValueError):
+        rv.kabsch_velocity_transform(P, Q[:2], vv)
+
+
 def test_velocity_transform(rv):
     rng = np.random.default_rng(3)
     R = rand_rtab(50); v = rng.standard_normal((50, 3))

@@ -220,3 +220,14 @@ def test_second_order_replays_are_consistent():
     np.testing.assert_allclose(ga, -th, rtol=1e-12)
     th, _ = orc.trapezoid_replay(a, a, t, 1.0, 1.0)
     np.testing.assert_allclose(th, 1.0 + 2.0 * 0.01 * i * (i + 1) / 2, rtol=1e-12)
+
+
+def test_kabsch_rotation(golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_kabsch.npz"))
+    for i in range(len(g["v"])):
+        R = orc.compute_rotation_kabsch(g["P"][i].copy(), g["Q"][i].copy())
+        np.testing.assert_allclose(R, g["R"][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(R.T @ R, np.eye(3), atol=1e-12)
+        assert np.linalg.det(R) == pytest.approx(1.0, abs=1e-12)
+    v, R = orc.kabsch_velocity_transform(g["P"], g["Q"], g["v"])
+    np.testing.assert_allclose(v, g["v_out"], rtol=1e-11, atol=1e-11)

@@ -243,6 +243,30 @@ def main():
              euler=np.stack(main_fun.integrate_theta_gamma(m_th, m_ga, Xs200, tt, -0.0342, -0.0522)),
              euler_last=np.stack(main_fun.integrate_theta_gamma(m_th2, m_ga2, Xs200, tt, -0.0342, -0.0522)))
 
+    # 8b. Kabsch rotation of cable-marker sets (velocity_transform_batch.py:8-19, exec'd def)
+    ns = {"np": np}
+    exec(extract_function(f"{REF}/velocity_transform_batch.py", "compute_rotation_kabsch"), ns)
+    kabsch = ns["compute_rotation_kabsch"]
+    Tn, Mn = 48, 16
+    Pm = np.empty((Tn, Mn, 3)); Qm = np.empty((Tn, Mn, 3)); Rk = np.empty((Tn, 3, 3))
+    for i in range(Tn):
+        # a hanging cable: nearly planar marker set, like the mocap data the reference processes
+        xs = np.linspace(0.0, rng.uniform(0.5, 2.0), Mn)
+        c = rng.uniform(0.8, 3.0)
+        pts = np.stack([xs, np.zeros(Mn), (np.cosh(c * (xs - xs.mean())) - 1) / c], axis=1)
+        if i % 6 == 5:
+            pts = rng.standard_normal((Mn, 3))                 # generic 3-D cloud
+        elif i % 6 != 4:
+            pts += 1e-3 * rng.standard_normal((Mn, 3))         # measurement noise (i%6==4: exactly planar)
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        Pm[i] = pts @ np.linalg.qr(rng.standard_normal((3, 3)))[0] + rng.uniform(-1, 1, 3)
+        Qm[i] = (Pm[i] - Pm[i].mean(0)) @ q.T + rng.uniform(-1, 1, 3) + 1e-4 * rng.standard_normal((Mn, 3))
+        Rk[i] = kabsch(Pm[i].copy(), Qm[i].copy())
+    vk = rng.standard_normal((Tn, 3)) * 100
+    np.savez(f"{OUT}/kat_kabsch.npz", P=Pm, Q=Qm, v=vk, R=Rk, v_out=np.einsum("tij,tj->ti", Rk, vk))
+
     # 9. trajectory generator outputs the reference already holds (data files)
     for c in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14):
         shutil.copyfile(f"{REF}/Results/Trajectory Data/rov_trajectory_exp{c}.csv",
