@@ -6,9 +6,9 @@
 // per-block best and (optionally) the trajectories are written.
 //
 //   phase 0  U chunk -> LDS (coalesced)                                  all threads
-//   phase 1  P1 prefix  P_{n+1} = P_n + (v_scale dt) U_n                 3*CK threads, N steps
-//   phase 2  exogenous feature rows (simply.py:25-31) of every node,     (N+1)*CK items
-//            scaled (scaler.pkl), + rotation axes (main_fun.py:75-103)
+//   phase 2  node positions P_n = P_0 + sum_{j<n} (v_scale dt) U_j,      (N+1)*CK items
+//            exogenous feature rows (simply.py:25-31), scaled (scaler.pkl),
+//            rotation axes (main_fun.py:75-103)
 //   phase 3  closed-loop RK4 / Euler over the horizon                    CK threads, N steps
 //            (simulate_rk4_theta_gamma.py:52-68 with the state fed back; velocity
 //             transform v_cat = R_theta(theta) R_gamma(-gamma) v when VT == COMPOSE)
@@ -197,7 +197,7 @@ __host__ __device__ inline int rollout_nx(int model, int vt) {
 __host__ __device__ inline int rollout_na(int model, int vt) {
     return vt == ROVMPC_VT_COMPOSE ? (model == MODEL_BUILTIN ? 5 : NAX) : 0;
 }
-constexpr int HDR = 40;            // header: block-best lane + mean[18] + inv_scale[18]
+constexpr int HDR = 48;            // header: flags (8 slots) + mean[18] + inv_scale[18] (+ pad)
 
 template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt) {
     size_t planes = 3 /*P*/ + 2 /*theta,gamma*/ + rollout_nx(model, vt) + rollout_na(model, vt);
@@ -223,7 +223,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 
     // carve LDS
     int *s_best_c = reinterpret_cast<int *>(smem);   // header
-    T *sMean = smem + 2, *sInv = smem + 20;          // scaler constants (lane-uniform reads)
+    T *sMean = smem + 8, *sInv = smem + 26;          // scaler constants (lane-uniform reads)
     const int US = (3 * N) | 1;                      // padded U row stride
     T *sP = smem + HDR;                              // 3 planes
     T *sY = sP + 3 * (N + 1) * CK;                   // theta, gamma planes
@@ -262,6 +262,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
         }
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
+
     }
     // state (uniform loads)
     const double *sd = a.state;
@@ -272,23 +273,6 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     __syncthreads();
 
     RV_STAMP(1);
-    // ---- phase 1: position prefix along the horizon ---------------------------------------
-    if (tid < 3 * CK) {
-        const int ax = tid / CK, c = tid % CK;
-        T p = (T)sd[3 + ax];
-        RV_PL(sP, ax, 0, c) = p;
-        // sequential sum in the reference's order; the next control is read one step ahead so
-        // the LDS latency stays off the dependent add
-        T unext = sU[c * US + ax];
-        for (int n = 0; n < N; ++n) {
-            const T ucur = unext;
-            if (n + 1 < N) unext = sU[c * US + (n + 1) * 3 + ax];
-            p = p + kk.vs_h * ucur;
-            RV_PL(sP, ax, n + 1, c) = p;
-        }
-    }
-    __syncthreads();
-
     RV_STAMP(2);
     // ---- phase 2: exogenous feature rows of every node ------------------------------------
     // V_n (feature-frame velocity at node n) when it does not depend on (theta, gamma)
@@ -303,8 +287,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         } else { vx = u[0]; vy = u[1]; vz = u[2]; }
     };
     for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
-        const int n = i / CK, c = i % CK;
-        const T Px = RV_PL(sP, 0, n, c), Py = RV_PL(sP, 1, n, c), Pz = RV_PL(sP, 2, n, c);
+        // far nodes first: with N*CK threads the one leftover round is then node 0 (no sum at all)
+        const int n = N - i / CK, c = i % CK;
+        // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
+        // sequential order by the item itself (independent LDS reads, no scan, no extra barrier)
+        T Px = (T)sd[3], Py = (T)sd[4], Pz = (T)sd[5];
+        {
+            const T *u = &sU[c * US];
+            for (int j = 0; j < n; ++j) {
+                Px = Px + kk.vs_h * u[3 * j]; Py = Py + kk.vs_h * u[3 * j + 1]; Pz = Pz + kk.vs_h * u[3 * j + 2];
+            }
+        }
+        RV_PL(sP, 0, n, c) = Px; RV_PL(sP, 1, n, c) = Py; RV_PL(sP, 2, n, c) = Pz;
         const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
         if (VT == ROVMPC_VT_COMPOSE) {
             V3<T> kt, kg;
@@ -377,6 +371,25 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
     };
 
+    // phase 4b, item (n, c): node n+1 of candidate c, needs (theta, gamma)_{n+1}: the theta-rotated
+    // end point, its catenary, the lowest z of the augmented shape (main_fun.py:38-111,
+    // fully_augmented_catenary.py:21-22) and the rest of the cost.
+    const Trig<T> trig4(false);
+    auto geometry_b_item = [&](int n, int c) {
+        const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
+                rz = RV_PL(sP, 2, n + 1, c) - P0z;
+        const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
+        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, kk.up, trig4);
+        const CatRoot<T> cr = solve_catenary_root<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi);   // Catenary(A, B')
+        const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
+        const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
+        const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
+        sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);
+    };
+    // Measured and rejected: letting the geometry waves chase the integrating wave node by node
+    // (LDS progress flags) -- a phase-4b item is a ~4 us dependent chain whatever the lane count, so
+    // the tail after the last integration step does not shrink and the extra waves slow the
+    // integrating one; phase 4b stays one parallel round after the join.
     if (MODEL == MODEL_BUILTIN) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
@@ -478,7 +491,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         };
         if (NT > nint) {
             if (tid < nint) {
-                // the integrating wave is the workgroup's critical path: it outranks the phase-4a
+                // the integrating wave is the workgroup's critical path: it outranks the geometry
                 // wave it may share a SIMD with
                 __builtin_amdgcn_s_setprio(3);
                 integrate();
@@ -586,7 +599,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
         };
         if (NT > nint) {
-            if (tid < nint) integrate(); else geometry_a(tid - nint, NT - nint);
+            if (tid < nint) {
+                integrate();
+            } else {
+                geometry_a(tid - nint, NT - nint);
+            }
         } else {
             integrate();
             geometry_a(tid, NT);
@@ -595,20 +612,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     __syncthreads();
 
     RV_STAMP(4);
-    // ---- phase 4b: per-node augmented-catenary lowest point and the rest of the cost --------
-    const Trig<T> trig4(false);
-    for (int i = tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) {
-        const int n = i / CK, c = i % CK;
-        const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
-                rz = RV_PL(sP, 2, n + 1, c) - P0z;
-        const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
-        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, kk.up, trig4);
-        const CatRoot<T> cr = solve_catenary_root<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi);   // Catenary(A, B')
-        const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
-        const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
-        const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
-        sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);
-    }
+    // ---- phase 4b ---------------------------------------------------------------------------
+    for (int i = tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) geometry_b_item(i / CK, i % CK);
     __syncthreads();
 
     RV_STAMP(5);

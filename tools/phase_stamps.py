@@ -13,7 +13,8 @@ import rovmpc  # noqa: E402
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 DBG = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-eng = rovmpc.Engine(rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG))
+CKB = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+eng = rovmpc.Engine(rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG, candidates_per_block=CKB))
 state, U = rovmpc.synthetic_problem(K, N)
 for _ in range(5):
     eng.step(state, U)
