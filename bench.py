@@ -231,6 +231,15 @@ def main():
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "note": "fp64 VALU/latency-bound by construction (~2-3 kFLOP of transcendental work "
                                        "per 24.4 B); see DESIGN.md"}
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs of this same command; MI355X_MICROARCH.md: KiB units, FETCH_SIZE reads half the
+        # bytes of a 16 B/lane coalesced stream on gfx950 -> doubled); only for the profiled workload.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if "roofline" in out and os.path.exists(pmc_path) and (args.N, args.K, args.dtype, world) == (20, 4096, "f64", 1):
+            pmc = json.load(open(pmc_path))
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                out["roofline"]["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.N)
         print(json.dumps(out))
