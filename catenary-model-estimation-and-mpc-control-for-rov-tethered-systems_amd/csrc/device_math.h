@@ -330,40 +330,26 @@ RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) 
     return up * best;
 }
 
-// Values of the four 16-lane rows of a wave, delivered to every row, without an LDS round
-// trip: v_permlane16_swap (odd rows of the first operand <-> even rows of the second) then
-// v_permlane32_swap (upper half of the first <-> lower half of the second), gfx950 only.
-// out[j] = v of lane (lane & 15) + 16 j.
-RV_DEV void rows4_u32(unsigned v, unsigned (&out)[4]) {
-    const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // (r0,r0,r2,r2), (r1,r1,r3,r3)
-    const auto e = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);   // r0 x4, r2 x4
-    const auto o = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false);   // r1 x4, r3 x4
-    out[0] = e[0]; out[2] = e[1]; out[1] = o[0]; out[3] = o[1];
+// The four lanes of a quad (lanes 4q .. 4q+3) each receive all four lanes' values:
+// out[j] = v of lane 4 (lane / 4) + j.  One v_mov_b32_dpp quad_perm per 32-bit half and source
+// lane -- a VALU move, no LDS round trip.  (Measured on MI355X for the role exchange of the
+// sequential phase: ds_bpermute ~150 cycles per exchange, v_permlane16/32_swap rows slower still.)
+template <int J> RV_DEV unsigned quad_bcast_u32(unsigned v) {
+    constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);          // quad_perm:[J,J,J,J]
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
 }
-#ifdef ROVMPC_ROWS4_PERMLANE
-RV_DEV void rows4(double v, double (&out)[4]) {
-    unsigned lo[4], hi[4];
-    rows4_u32((unsigned)__double2loint(v), lo);
-    rows4_u32((unsigned)__double2hiint(v), hi);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __hiloint2double((int)hi[j], (int)lo[j]);
+RV_DEV void quad4(double v, double (&out)[4]) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    out[0] = __hiloint2double((int)quad_bcast_u32<0>(hi), (int)quad_bcast_u32<0>(lo));
+    out[1] = __hiloint2double((int)quad_bcast_u32<1>(hi), (int)quad_bcast_u32<1>(lo));
+    out[2] = __hiloint2double((int)quad_bcast_u32<2>(hi), (int)quad_bcast_u32<2>(lo));
+    out[3] = __hiloint2double((int)quad_bcast_u32<3>(hi), (int)quad_bcast_u32<3>(lo));
 }
-RV_DEV void rows4(float v, float (&out)[4]) {
-    unsigned u[4];
-    rows4_u32(__float_as_uint(v), u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __uint_as_float(u[j]);
+RV_DEV void quad4(float v, float (&out)[4]) {
+    const unsigned u = __float_as_uint(v);
+    out[0] = __uint_as_float(quad_bcast_u32<0>(u)); out[1] = __uint_as_float(quad_bcast_u32<1>(u));
+    out[2] = __uint_as_float(quad_bcast_u32<2>(u)); out[3] = __uint_as_float(quad_bcast_u32<3>(u));
 }
-#else
-// Measured on MI355X: the ds_bpermute form (pipelined through the LDS crossbar) is ~0.12 us per
-// horizon step faster than the permlane-swap form, whose 18 swaps per step each carry a
-// two-wait-state hazard.
-template <typename T> RV_DEV void rows4(T v, T (&out)[4]) {
-    const int c16 = threadIdx.x & 15;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = __shfl(v, c16 + 16 * j, 64);
-}
-#endif
 
 // order-preserving double <-> int64 map (signed compare of keys == IEEE compare of values)
 RV_DEV long long ordered_key(double v) {

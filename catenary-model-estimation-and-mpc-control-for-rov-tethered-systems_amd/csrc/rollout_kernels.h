@@ -206,6 +206,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
     e += (size_t)CK * N;                             // node costs
     if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
+    if (model == MODEL_BUILTIN) e += (size_t)8 * N;                          // candidate-invariant gamma path
     return e;
 }
 
@@ -232,6 +233,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *sU = sA + NA * (N + 1) * CK;                  // [c][n][3]
     T *sC = sU + CK * US;                            // [n][c] node costs
     T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
+    T *sG = sC + CK * N;                             // compiled-in model: gamma-path table [N][8]
+    int *s_prog = s_best_c + 2;                      // gamma-path steps published so far
 
     RV_STAMP(0);
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
@@ -262,6 +265,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
         }
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
+        if (tid == 0) *s_prog = 0;
 
     }
     // state (uniform loads)
@@ -394,33 +398,75 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
         // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
-        // Of the 18 slots only x3, x15, x16, x17 are read, and every sine argument of a step is
-        // known once (theta_n, gamma_n) are.  The phase is sequential in n and issue-bound on
-        // fp64 trig, so each candidate gets FOUR lanes (c + 16 j, j = role = wave row): the four
-        // trigonometric evaluations that open a step -- sincos(theta_n), sincos(gamma_n),
-        // sin(x17 at t_n+1), sin(x17 at the midpoint) -- run as ONE sincos over the wave, the two
-        // that close it -- sin(x3 at t_n+1), sin(x3 at the midpoint) -- as one more; the row
-        // values reach the other rows through v_permlane16/32_swap.  All four lanes carry the
-        // (cheap) state update redundantly, so no other exchange is needed.
-        const int nint = ((CK + 15) / 16) * 64;
-        auto integrate = [&]() {
-            const int lane = tid & 63, c16 = lane & 15, role = lane >> 4;
+        // Of the 18 slots only x3, x15, x16, x17 are read.  Two structural facts of these rows
+        // shape the phase:
+        //  * dgamma/dt reads gamma and its delay slot only -- no control, no theta.  The gamma
+        //    path is therefore the SAME for every candidate of the step (they share the state):
+        //    one wave (the "gamma wave") integrates it once per workgroup and publishes, per
+        //    horizon step, sincos(gamma_n), the three sines of the x17 slot and gamma_{n+1} in an
+        //    LDS table; the theta waves consume entry n at step n (LDS progress word; LDS is
+        //    coherent within the CU and one wave's DS operations complete in order).
+        //  * every sine argument of a theta step is known once (theta_n, gamma_n) are: each
+        //    candidate owns a quad (lane = 4 c + role); the two closing sines -- sin(x3 at t_n+1),
+        //    sin(x3 at the midpoint) -- are ONE sincos over the wave, exchanged inside the quad with
+        //    DPP quad_perm moves; all four lanes carry the cheap state update redundantly.
+        const int nint = ((CK + 15) / 16) * 64;            // theta waves
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+        const bool euler = a.integrator == ROVMPC_EULER;
+        const int nsteps = (a.debug & 1) ? 0 : N;
+
+        // gamma path, one quad's worth of work: role 1 sincos(gamma_n), role 2 sin(x17 at t_n+1),
+        // role 3 sin(x17 at the midpoint)
+        auto gamma_path = [&]() {
+            const int role = tid & 3;
+            const Trig<T> trig(true);
+            const T m15 = sMean[15], i15 = sInv[15], m17 = sMean[17], i17 = sInv[17];
+            const T hstep = kk.h, hh = T(0.5) * hstep, h6 = hstep / T(6);
+            T ga = ga0, gam = gam0;
+            T s17a = (gam - m17) * i17;
+            T sinA = trig.sin(s17a);
+            for (int n = 0; n < nsteps; ++n) {
+                const T s17b = (ga - m17) * i17;                               // np.roll delay slot, simply.py:35-38
+                const T p17m = hold ? s17a : (s17a + s17b) / T(2);
+                const T p17e = hold ? s17a : s17b;
+                T sv, cv, sr[4], cr4[4];
+                trig.sincos(role == 2 ? s17b : (role == 3 ? p17m : ga), &sv, &cv);
+                quad4(sv, sr); quad4(cv, cr4);
+                const T sinB = sr[2];
+                const T sinM = hold ? sinA : sr[3], sinE = hold ? sinA : sinB;
+                const T k1g = (ga - m15) * i15 - s17a;
+                T gan;
+                if (euler) {
+                    gan = ga + k1g * hstep;                                    // main_fun.py:762
+                } else {
+                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
+                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
+                    const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
+                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);     // :66
+                }
+                if ((tid & 63) == 0) {
+                    T *g = sG + 8 * n;
+                    g[0] = sr[1]; g[1] = cr4[1]; g[2] = sinA; g[3] = sinM; g[4] = sinE; g[5] = gan;
+                    __hip_atomic_store(s_prog, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                gam = ga; ga = gan; s17a = s17b; sinA = sinB;
+            }
+            if ((tid & 63) == 0) __hip_atomic_store(s_prog, N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+
+        auto theta_path = [&]() {
+            const int lane = tid & 63, c16 = lane >> 2, role = lane & 3;
             const int cc = (tid >> 6) * 16 + c16;               // candidate of this lane
             const bool live = cc < CK;
             const int c = live ? cc : CK - 1;                   // clamp reads of padding lanes
-            const int nsteps = (a.debug & 1) ? 0 : N;
             const Trig<T> trig(true);
-            const T m3 = sMean[3], i3 = sInv[3], m15 = sMean[15], i15 = sInv[15];
-            const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
-            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
-            const bool euler = a.integrator == ROVMPC_EULER;
-            const T hh = T(0.5) * kk.h, h6 = kk.h / T(6);
+            const T m3 = sMean[3], i3 = sInv[3], m16 = sMean[16], i16 = sInv[16];
+            const T hstep = kk.h, h6 = hstep / T(6);            // kk lives in memory: no use inside the loop
             const T KT = T(0.048152514);
-            T th = th0, ga = ga0, thm = thm0, gam = gam0;
-            if (live && role == 0) { RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga; }
+            T th = th0, thm = thm0;
+            if (live && role == 0) { RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga0; }
             T x3a = (V0x - m3) * i3;
-            T s17a = (gam - m17) * i17;
-            T sinA = trig.sin(s17a), sinXa = trig.sin(x3a);
+            T sinXa = trig.sin(x3a);
             // operands of the velocity transform of step 0 (prefetched one step ahead below)
             T ktx = T(0), kty = T(0), kgx = T(0), kgy = T(0), kgz = T(0), u0 = T(0), u1 = T(0), u2 = T(0), x3n = T(0);
             auto fetch = [&](int n) {
@@ -435,26 +481,22 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             };
             if (nsteps > 0) fetch(0);
             for (int n = 0; n < nsteps; ++n) {
-                // delay slots x16, x17 at the two ends of the step (np.roll semantics, simply.py:35-38)
+                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
-                const T s17b = (ga - m17) * i17;
-                const T p17m = hold ? s17a : (s17a + s17b) / T(2);
-                const T arg1 = role == 0 ? th : (role == 1 ? ga : (role == 2 ? s17b : p17m));
-                T sv, cv;
-                trig.sincos(arg1, &sv, &cv);
-                T sr[4], cr4[4];
-                rows4(sv, sr);
-                const T sinB = sr[2], sinMr = sr[3];
+                T st = T(0), ct = T(1);
+                if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
+                while (__hip_atomic_load(s_prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n) __builtin_amdgcn_s_sleep(1);
+                const T *g = sG + 8 * n;
+                const T sg = g[0], cg = g[1], sinA = g[2], sinM = g[3], sinE = g[4], gan = g[5];
                 T x3b;
                 if (VT == ROVMPC_VT_COMPOSE) {
                     // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world with the
                     // cable axes at node n (R @ v of velocity_transform_batch.py:100-101, R composed
                     // from the augmentation angles); only its x component feeds x3
-                    rows4(cv, cr4);
                     const V3<T> kt = {ktx, kty, T(0)};
                     const V3<T> kg = {kgx, kgy, kgz};
-                    V3<T> v = rodrigues_unit<T>({u0, u1, u2}, kg, -sr[1], cr4[1]);
-                    v = rodrigues_unit<T>(v, kt, sr[0], cr4[0]);
+                    V3<T> v = rodrigues_unit<T>({u0, u1, u2}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
                     x3b = (v.x - m3) * i3;
                 } else {
                     x3b = x3n;
@@ -463,44 +505,43 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 const T x3m = (x3a + x3b) / T(2);                             // :62 feature midpoint
                 const T s2 = trig.sin((role & 1) ? x3m : x3b);
                 T s2r[4];
-                rows4(s2, s2r);
+                quad4(s2, s2r);
                 const T sinXb = s2r[0], sinXm = s2r[1];
                 const T k1t = (((sinA - sinXa) - s16a) - x3a) * KT;
-                const T k1g = (ga - m15) * i15 - s17a;
-                T thn, gan;
+                T thn;
                 if (euler) {
-                    thn = th + k1t * kk.h;                                     // main_fun.py:761
-                    gan = ga + k1g * kk.h;
+                    thn = th + k1t * hstep;                                   // main_fun.py:761
                 } else {
                     const T p16m = hold ? s16a : (s16a + s16b) / T(2);
-                    const T p16e = hold ? s16a : s16b, p17e = hold ? s17a : s17b;
-                    const T sinM = hold ? sinA : sinMr;
-                    const T sinE = hold ? sinA : sinB;
+                    const T p16e = hold ? s16a : s16b;
                     const T k2t = (((sinM - sinXm) - p16m) - x3m) * KT, k3t = k2t;
                     const T k4t = (((sinE - sinXb) - p16e) - x3b) * KT;
-                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
-                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
-                    const T k4g = ((ga + kk.h * k3g) - m15) * i15 - p17e;
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
-                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
-                thm = th; gam = ga; th = thn; ga = gan;
-                x3a = x3b; sinXa = sinXb; s17a = s17b; sinA = sinB;
-                if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga; }
+                thm = th; th = thn;
+                x3a = x3b; sinXa = sinXb;
+                if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = gan; }
             }
         };
-        if (NT > nint) {
+
+        if (NT >= nint + 64) {
+            // theta waves | one gamma wave | the rest: phase 4a
             if (tid < nint) {
-                // the integrating wave is the workgroup's critical path: it outranks the geometry
-                // wave it may share a SIMD with
-                __builtin_amdgcn_s_setprio(3);
-                integrate();
+                __builtin_amdgcn_s_setprio(3);       // the workgroup's critical path
+                theta_path();
                 __builtin_amdgcn_s_setprio(0);
+            } else if (tid < nint + 64) {
+                __builtin_amdgcn_s_setprio(2);
+                gamma_path();
+                __builtin_amdgcn_s_setprio(0);
+                geometry_a(tid - nint, NT - nint);
             } else {
                 geometry_a(tid - nint, NT - nint);
             }
         } else {
-            integrate();
+            if (tid < 64) gamma_path();              // tiny workgroups: gamma path first, same wave
+            __syncthreads();
+            if (tid < nint) theta_path();
             geometry_a(tid, NT);
         }
     } else {
@@ -516,7 +557,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
             const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
             const bool euler = a.integrator == ROVMPC_EULER;
-            const T hh = T(0.5) * kk.h, h6 = kk.h / T(6);
+            const T hstep = kk.h, inv_hstep = kk.inv_h;
+            const T hh = T(0.5) * hstep, h6 = hstep / T(6);
             // generic path: full 18-slot feature row per stage, bytecode interpreter
             T Vx = V0x, Vy = V0y, Vz = V0z;
             auto store_vslots = [&](int node, T vx, T vy, T vz, T ax, T ay, T az) {
@@ -543,7 +585,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T *u = &sU[c * US + n * 3];
                     V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
                     v = rodrigues_unit<T>(v, kt, st, ct);
-                    store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * kk.inv_h, (v.y - Vy) * kk.inv_h, (v.z - Vz) * kk.inv_h);
+                    store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
@@ -584,13 +626,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 stage(th, ga, 0, k1t, k1g);
                 T thn, gan;
                 if (euler) {
-                    thn = th + k1t * kk.h;                                     // main_fun.py:761
-                    gan = ga + k1g * kk.h;
+                    thn = th + k1t * hstep;                                     // main_fun.py:761
+                    gan = ga + k1g * hstep;
                 } else {
                     T k2t, k2g, k3t, k3g, k4t, k4g;
                     stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
                     stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
-                    stage(th + kk.h * k3t, ga + kk.h * k3g, 2, k4t, k4g);
+                    stage(th + hstep * k3t, ga + hstep * k3g, 2, k4t, k4g);
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
