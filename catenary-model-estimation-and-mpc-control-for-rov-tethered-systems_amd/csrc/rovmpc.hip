@@ -884,6 +884,30 @@ extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out
 }
 #endif
 
+extern "C" int rovmpc_extract_features(rovmpc_handle *h, const double *P0, const double *P1, const double *V1, const double *time,
+                                       const double *theta, const double *gamma, int64_t T, int32_t with_prev, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (T < 2 || !P0 || !P1 || !V1 || !time || !theta || !gamma || !out)
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_extract_features: bad argument (np.gradient needs at least 2 rows)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int F = with_prev ? 18 : 16;
+    DevBuf d0, d1, dv, dt, dth, dga, dout;
+    UPLOAD(h, d0, P0, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, d1, P1, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, dv, V1, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, dt, time, (size_t)T * sizeof(double));
+    UPLOAD(h, dth, theta, (size_t)T * sizeof(double));
+    UPLOAD(h, dga, gamma, (size_t)T * sizeof(double));
+    HIPCHK(h, dout.alloc((size_t)T * F * sizeof(double)));
+    hipLaunchKernelGGL(extract_features_kernel, dim3(grid_for(T, 256)), dim3(256), 0, h->stream, d0.as<double>(), d1.as<double>(),
+                       dv.as<double>(), dt.as<double>(), dth.as<double>(), dga.as<double>(), (long long)T, with_prev,
+                       dout.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dout.p, (size_t)T * F * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_kabsch_velocity_transform(rovmpc_handle *h, const double *P, const double *Q, const double *v, int64_t T,
                                                 int32_t M, int32_t batch_gates, double *v_out, double *R_out) {
     if (!h) return ROVMPC_ERR_INVALID;

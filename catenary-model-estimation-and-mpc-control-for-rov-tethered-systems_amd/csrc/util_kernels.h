@@ -230,6 +230,40 @@ velocity_transform_kernel(const double *R, const double *v, long long n, double 
     out[3 * i + 2] = r[6] * u[0] + r[7] * u[1] + r[8] * u[2];
 }
 
+// np.gradient(f, t) at row i of a length-T column with stride `ld` (numpy's non-uniform
+// second-order interior formula, first-order one-sided edges; T == 1 is rejected by the host).
+RV_DEV double np_gradient(const double *f, const double *t, long long i, long long T, int ld) {
+    if (i == 0) return (f[ld] - f[0]) / (t[1] - t[0]);
+    if (i == T - 1) return (f[(T - 1) * ld] - f[(T - 2) * ld]) / (t[T - 1] - t[T - 2]);
+    const double dx1 = t[i] - t[i - 1], dx2 = t[i + 1] - t[i];
+    const double a = -(dx2) / (dx1 * (dx1 + dx2)), b = (dx2 - dx1) / (dx1 * dx2), c = dx1 / (dx2 * (dx1 + dx2));
+    return a * f[(i - 1) * ld] + b * f[i * ld] + c * f[(i + 1) * ld];
+}
+
+// extract_features (simply.py:15-41), one lane per row.
+__global__ void __launch_bounds__(256)
+extract_features_kernel(const double *__restrict__ P0, const double *__restrict__ P1, const double *__restrict__ V1,
+                        const double *__restrict__ time, const double *__restrict__ theta,
+                        const double *__restrict__ gamma, long long T, int with_prev, double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int F = with_prev ? 18 : 16;
+    double *o = out + i * F;
+    const double *p1 = P1 + 3 * i, *p0 = P0 + 3 * i, *v = V1 + 3 * i;
+    const double rx = p1[0] - p0[0], ry = p1[1] - p0[1], rz = p1[2] - p0[2];          // :25
+    const double nr = m_sqrt(rx * rx + ry * ry + rz * rz);
+    const double ux = rx / (nr + 1e-8), uy = ry / (nr + 1e-8), uz = rz / (nr + 1e-8);  // :26
+    const double nv = m_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) + 1e-8;           // :30
+    o[0] = p1[0]; o[1] = p1[1]; o[2] = p1[2];
+    o[3] = v[0]; o[4] = v[1]; o[5] = v[2];
+    for (int a = 0; a < 3; ++a) o[6 + a] = np_gradient(V1 + a, time, i, T, 3);         // :20-23
+    o[9] = ux; o[10] = uy; o[11] = uz;
+    o[12] = m_clip(nr, 1e-5, 10.0);                                                     // :27
+    o[13] = m_clip((v[0] * ux + v[1] * uy + v[2] * uz) / nv, -1.0, 1.0);                // :29-31
+    o[14] = theta[i]; o[15] = gamma[i];
+    if (with_prev) { o[16] = theta[i > 0 ? i - 1 : 0]; o[17] = gamma[i > 0 ? i - 1 : 0]; }   // :35-38
+}
+
 // compute_rotation_kabsch (velocity_transform_batch.py:8-19) + the per-frame gates of :75-101,
 // one lane per frame.  H = Pc^T Qc = U S V^T; R = V U^T with the reflection fix.  A proper
 // rotation that maps u1 -> v1 and u2 -> v2 is unique, so R needs only the two dominant singular

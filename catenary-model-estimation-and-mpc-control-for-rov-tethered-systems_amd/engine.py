@@ -321,6 +321,17 @@ class Engine:
         return out
 
 
+    def extract_features(self, P0, P1, V1, time, theta, gamma, with_prev: bool = True) -> np.ndarray:
+        c = lambda x, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), shape))
+        time = np.ascontiguousarray(time, np.float64).reshape(-1)
+        T = time.shape[0]
+        P0, P1, V1 = c(P0, (T, 3)), c(P1, (T, 3)), c(V1, (T, 3))
+        theta, gamma = c(np.asarray(theta, np.float64).reshape(-1), (T,)), c(np.asarray(gamma, np.float64).reshape(-1), (T,))
+        out = np.empty((T, 18 if with_prev else 16))
+        self._check(self.lib.rovmpc_extract_features(self._h, _ptr(P0), _ptr(P1), _ptr(V1), _ptr(time), _ptr(theta),
+                                                     _ptr(gamma), T, int(with_prev), _ptr(out)))
+        return out
+
     def kabsch_velocity_transform(self, P, Q, v, batch_gates: bool = True):
         P = np.ascontiguousarray(P, np.float64); Q = np.ascontiguousarray(Q, np.float64)
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3)

@@ -1,13 +1,21 @@
-"""Host-side feature map of generation 1 (simply.py:15-41; main_fun.py:167-193 is the same
-without the two ``_prev`` columns).  Off the hot path: inside the rollout the same rows are
-built per (candidate, node) by the HIP kernel."""
+"""Feature map of generation 1 (simply.py:15-41; main_fun.py:167-193 is the same without the
+two ``_prev`` columns).  ``extract_features`` / ``extract_features_arrays`` run on the GPU
+(``rovmpc_extract_features``); ``extract_features_host`` is the plain NumPy statement kept for
+boxes without a GPU (data preparation only -- it is not on any rollout path).  Inside the
+rollout the same rows are built per (candidate, node) by the fused kernel."""
 from __future__ import annotations
 
 import numpy as np
 
 
 def extract_features_arrays(P0, P1, V1, time, theta, gamma, with_prev: bool = True) -> np.ndarray:
-    """P0, P1 in metres (the reference divides its mm columns by 1000 first), V1 raw."""
+    """P0, P1 in metres (the reference divides its mm columns by 1000 first), V1 raw.  GPU."""
+    from .engine import default_engine
+    return default_engine().extract_features(P0, P1, V1, time, theta, gamma, with_prev)
+
+
+def extract_features_host(P0, P1, V1, time, theta, gamma, with_prev: bool = True) -> np.ndarray:
+    """NumPy statement of the same map (no GPU needed)."""
     P0 = np.asarray(P0, float); P1 = np.asarray(P1, float); V1 = np.asarray(V1, float)
     time = np.asarray(time, float)
     A1 = np.stack([np.gradient(V1[:, j], time) for j in range(3)], axis=1)

@@ -246,6 +246,15 @@ int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B
 int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, const double *v,
                               int64_t n, double *out);
 
+/* extract_features (simply.py:15-41; main_fun.py:167-193 when with_prev = 0) for T rows:
+ * P0, P1 [T][3] in metres, V1 [T][3], time [T], theta [T], gamma [T] ->
+ * out[T][18] (or [T][16]) = [P1, V1, A1 = np.gradient(V1, time), unit_rel, tension, angle_proj,
+ * theta, gamma (, theta_prev, gamma_prev)]; np.gradient's second-order non-uniform interior
+ * stencil and first-order edges. */
+int rovmpc_extract_features(rovmpc_handle *h, const double *P0, const double *P1, const double *V1,
+                            const double *time, const double *theta, const double *gamma,
+                            int64_t T, int32_t with_prev, double *out);
+
 /* velocity_transform_batch.py:8-19,71-107 (batch_gates = 1) / velocity_transform.py:42-80
  * (batch_gates = 0) for T frames of M cable markers: R = Kabsch rotation of the centred marker
  * sets P[T][M][3] -> Q[T][M][3] (3x3 SVD with the reflection fix), v_out = R @ v.

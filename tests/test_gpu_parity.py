@@ -209,6 +209,18 @@ def test_kabsch_velocity_transform(rv, orc, golden_dir):
         rv.kabsch_velocity_transform(P, Q[:2], vv)
 
 
+def test_extract_features_gpu(rv, golden_dir):
+    """simply.py:15-41 / main_fun.py:167-193 on the GPU (np.gradient with non-uniform time) against the
+    reference's own outputs."""
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "kat_features.npz"))
+    df = pd.DataFrame(g["frame"], columns=[str(c) for c in g["columns"]])
+    np.testing.assert_allclose(rv.extract_features(df), g["X18"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(rv.extract_features(df, with_prev=False), g["X16"], rtol=1e-12, atol=1e-13)
+    with pytest.raises(rv.RovmpcError):
+        rv.extract_features_arrays(np.zeros((1, 3)), np.ones((1, 3)), np.ones((1, 3)), [0.0], [0.0], [0.0])
+
+
 def test_velocity_transform(rv):
     rng = np.random.default_rng(3)
     R = rand_rtab(50); v = rng.standard_normal((50, 3))

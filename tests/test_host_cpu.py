@@ -205,8 +205,11 @@ def test_feature_map(golden_dir):
     import pandas as pd
     g = np.load(os.path.join(golden_dir, "kat_features.npz"))
     df = pd.DataFrame(g["frame"], columns=[str(c) for c in g["columns"]])
-    np.testing.assert_allclose(rovmpc.extract_features(df), g["X18"], rtol=1e-13, atol=1e-15)
-    np.testing.assert_allclose(rovmpc.extract_features(df, with_prev=False), g["X16"], rtol=1e-13, atol=1e-15)
+    fr = g["frame"]
+    args = (fr[:, 0:3] / 1000, fr[:, 3:6] / 1000, fr[:, 6:9], fr[:, 11], fr[:, 9], fr[:, 10])
+    np.testing.assert_allclose(rovmpc.extract_features_host(*args), g["X18"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(rovmpc.extract_features_host(*args, with_prev=False), g["X16"], rtol=1e-13, atol=1e-15)
+    assert list(df.columns[:3]) == ["rod_end X", "rod_end Y", "rod_end Z"]
 
 
 def test_state_and_shape_validation():
