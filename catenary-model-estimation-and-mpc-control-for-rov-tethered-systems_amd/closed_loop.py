@@ -1,10 +1,11 @@
 """Closed-loop driver: an MPC step per sample of a synthetic ROV trajectory (BASELINE config 5).
 
-Plant model (build-defined; the reference has none): the anchor P0 follows ROV 2 and the
-cable attach point P1 follows ROV 1 of the generated trajectory (Rov_traj_gen.py cases), the
-measured velocity is their finite difference, and (theta, gamma) advance by the first step
-of the chosen candidate's predicted trajectory.  Everything per step stays on the device:
-candidates are pre-sampled in HBM, the state update is a tiny torch op.
+Plant model (build-defined; the reference has none): the anchor P0 follows ROV 2 and the cable
+attach point P1 follows ROV 1 of the generated trajectory (Rov_traj_gen.py cases), the measured
+velocity / acceleration are their finite differences, and (theta, gamma) advance to the first
+predicted node of the chosen candidate.  Everything per step stays on the device: candidate
+batches are pre-sampled in HBM, the plant update is a one-workgroup kernel, and the whole loop is
+enqueued by ONE library call (``rovmpc_closed_loop_device``) with no host synchronisation.
 """
 from __future__ import annotations
 
@@ -30,46 +31,50 @@ class ClosedLoopReport:
     cost: np.ndarray         # (steps,)
 
 
-def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_pools: int = 8,
-                    seed: int = 0, sharded=None) -> ClosedLoopReport:
-    import torch
+def closed_loop_inputs(engine: Engine, exp_case: int, n_steps: int, seed: int = 0):
+    """(rows (n_steps, 16) in rovmpc_state order, initial state (16,)).  P0/P1/V1/A1 come from the
+    generated two-ROV trajectory; the measured (theta, gamma) are a smooth bounded synthetic signal
+    around the scaler means (the reference's recorded angles are not in the snapshot)."""
     cfg = engine.cfg
-    dev = torch.device("cuda", cfg.device)
-    tdt = torch.float64 if cfg.dtype == "f64" else torch.float32
     total_time = n_steps * cfg.dt
-    _, t0, t1 = generate_rov_trajectories(exp_case, n_steps + 1, total_time, seed=seed)
+    t, t0, t1 = generate_rov_trajectories(exp_case, n_steps + 1, total_time, seed=seed)
     P1 = t0[0:3].T.copy(); P0 = t1[0:3].T.copy()
     P1[:, 2] += 0.3                                            # keep the cable off the degenerate flat case
     V = np.gradient(P1, cfg.dt, axis=0) / cfg.v_scale          # m/s -> rob_cor_speed units
     A = np.gradient(V, cfg.dt, axis=0)
-    mean = engine.model.mean; scale = engine.model.scale
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    pools = [(torch.tensor(mean[3:6], device=dev) + torch.tensor(scale[3:6], device=dev)
-              * torch.randn((cfg.K, cfg.N, 3), generator=g, device=dev, dtype=torch.float64)).to(tdt).contiguous()
-             for _ in range(n_pools)]
-    exo = torch.tensor(np.hstack([P0, P1, V, A]), device=dev)  # (steps+1, 12)
-    state = torch.empty(16, dtype=torch.float64, device=dev)
-    state[12] = state[14] = float(mean[14]); state[13] = state[15] = float(mean[15])
+    mean, scale = engine.model.mean, engine.model.scale
+    th = mean[14] + scale[14] * np.sin(2 * np.pi * t / 7.0)
+    ga = mean[15] + scale[15] * np.cos(2 * np.pi * t / 11.0)
+    thp = np.roll(th, 1); gap = np.roll(ga, 1); thp[0] = th[0]; gap[0] = ga[0]
+    rows = np.ascontiguousarray(np.hstack([P0, P1, V, A, th[:, None], ga[:, None], thp[:, None], gap[:, None]])[:n_steps])
+    return rows, rows[0].copy()
+
+
+def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_pools: int = 8,
+                    seed: int = 0, k_offset: int = 0, feedback: bool = False) -> ClosedLoopReport:
+    """Runs the loop on ``engine``'s device.  If the engine has a native communicator
+    (``Engine.comm_init``) every step is the candidate-sharded one.  ``feedback=True`` replaces the
+    measured (theta, gamma) by the model's own first predicted node from the second step on."""
+    import torch
+    cfg = engine.cfg
+    dev = torch.device("cuda", cfg.device)
+    tdt = torch.float64 if cfg.dtype == "f64" else torch.float32
+    exo_np, state_np = closed_loop_inputs(engine, exp_case, n_steps, seed)
+    mean = torch.tensor(engine.model.mean[3:6], device=dev); scale = torch.tensor(engine.model.scale[3:6], device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(seed + 1000 * k_offset)
+    pools = (mean + scale * torch.randn((n_pools, cfg.K, cfg.N, 3), generator=g, device=dev, dtype=torch.float64)).to(tdt).contiguous()
+    exo = torch.tensor(exo_np, device=dev)
+    state = torch.tensor(state_np, device=dev)
     R = engine.result_len
     results = torch.empty((n_steps, R), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream()
     torch.cuda.synchronize()
     t_start = _time.perf_counter()
-    for i in range(n_steps):
-        state[0:12] = exo[i]
-        if sharded is not None:
-            rec = sharded.step_device(state, pools[i % n_pools])
-            sharded.synchronize()
-            results[i] = rec
-        else:
-            engine.step_device(state.data_ptr(), pools[i % n_pools].data_ptr(), results[i].data_ptr(), stream.cuda_stream)
-            rec = results[i]
-        # plant: theta/gamma follow the first predicted step of the chosen candidate
-        state[14] = state[12]; state[15] = state[13]
-        state[12] = rec[7]; state[13] = rec[8]
+    engine.closed_loop_device(exo.data_ptr(), n_steps, state.data_ptr(), pools.data_ptr(), n_pools, results.data_ptr(),
+                              k_offset, feedback, stream.cuda_stream)
     torch.cuda.synchronize()
     wall = _time.perf_counter() - t_start
     res = results.cpu().numpy()
-    tg = np.vstack([res[0, 5:7], res[:, 7:9]])
+    tg = np.vstack([res[0, 5:7], res[:, 7:9]])                  # start state, then each step's first predicted node
     sim = n_steps * cfg.dt
     return ClosedLoopReport(n_steps, wall, sim, sim / wall, n_steps * cfg.K * cfg.N / wall, res[:, 2:5], tg, res[:, 0])

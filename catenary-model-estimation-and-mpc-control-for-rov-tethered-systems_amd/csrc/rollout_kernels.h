@@ -781,4 +781,21 @@ select_kernel(const long long *slots, int world, int R, double *result) {
     for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = ordered_val(slots[(size_t)rb * R + i]);
 }
 
+// Plant update of the closed-loop driver (one tiny workgroup): exogenous slots from the measured
+// trajectory row, (theta, gamma) advanced to the first predicted node of the previous winner.
+__global__ void __launch_bounds__(64)
+plant_update_kernel(double *state, const double *exo_row, const double *prev_result) {
+    const int t = threadIdx.x;
+    if (prev_result) {          // feedback: keep the model's own (theta, gamma), take the rest from the row
+        if (t < 12) state[t] = exo_row[t];
+        if (t == 12) {
+            const double th = state[12], ga = state[13];
+            state[14] = th; state[15] = ga;
+            state[12] = prev_result[7]; state[13] = prev_result[8];   // record: [J, k, u(3), th0, ga0, th1, ga1, ...]
+        }
+    } else if (t < 16) {
+        state[t] = exo_row[t];
+    }
+}
+
 }  // namespace rovmpc

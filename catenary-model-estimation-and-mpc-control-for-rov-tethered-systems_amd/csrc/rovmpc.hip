@@ -1121,3 +1121,33 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     h->comm_stream = nullptr;
     return ROVMPC_OK;
 }
+
+// ---- closed loop ----------------------------------------------------------------------------------
+
+extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state, const void *d_pools,
+                                         int32_t n_pools, int64_t k_offset, int32_t feedback, double *d_results, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (T < 1 || n_pools < 1 || !d_exo || !d_state || !d_pools || !d_results)
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_closed_loop_device: bad argument");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t R = rovmpc_result_len(h);
+    const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * h->esz;
+    for (int64_t i = 0; i < T; ++i) {
+        const double *prev = (feedback && i > 0) ? d_results + (size_t)(i - 1) * R : nullptr;
+        if (h->comm && prev) {
+            // the previous global record is produced on the side stream
+            rc = rovmpc_comm_join(h, s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo + (size_t)i * 16, prev);
+        HIPCHK(h, hipGetLastError());
+        const void *U = (const char *)d_pools + (size_t)(i % n_pools) * pool_bytes;
+        if (h->comm) rc = rovmpc_step_device_allreduce(h, d_state, U, k_offset, d_results + (size_t)i * R, s);
+        else rc = enqueue_step(h, d_state, U, nullptr, d_results + (size_t)i * R, 0, nullptr, 0, 1, s);
+        if (rc) return rc;
+    }
+    if (h->comm) return rovmpc_comm_join(h, s);
+    return ROVMPC_OK;
+}

@@ -252,6 +252,11 @@ class Engine:
     def comm_destroy(self):
         self._check(self.lib.rovmpc_comm_destroy(self._h))
 
+    def closed_loop_device(self, d_exo: int, T: int, d_state: int, d_pools: int, n_pools: int, d_results: int,
+                           k_offset: int = 0, feedback: bool = False, stream: int = 0):
+        self._check(self.lib.rovmpc_closed_loop_device(self._h, d_exo, T, d_state, d_pools, n_pools, k_offset,
+                                                       int(feedback), d_results, stream))
+
     def timing_enable(self, max_launches: int):
         self._check(self.lib.rovmpc_timing_enable(self._h, max_launches))
 

@@ -198,6 +198,18 @@ int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const 
 int rovmpc_comm_join(rovmpc_handle *h, void *stream);   /* make `stream` wait for the side stream */
 int rovmpc_comm_destroy(rovmpc_handle *h);
 
+/* Closed loop, device resident (BASELINE config 5): for i = 0..T-1 enqueue, without any host
+ * synchronisation, (1) the plant update -- state = exo[i] (16 doubles per step in rovmpc_state
+ * order: the measured P0, P1, V1, A1, theta, gamma, theta_prev, gamma_prev); with feedback != 0,
+ * from the second step on, theta/gamma_prev = theta/gamma and (theta, gamma) = the first predicted
+ * node of the previous step's winner instead of the measured values -- and (2) one MPC step on
+ * candidate batch pools[i % n_pools], record into results[i][result_len].  If rovmpc_comm_init
+ * was called the step is the sharded one (all-reduce(min) per step; with feedback the plant
+ * update then waits for the global record). */
+int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
+                              const void *d_pools, int32_t n_pools, int64_t k_offset,
+                              int32_t feedback, double *d_results, void *stream);
+
 /* Per-launch timing of the rollout kernel with HIP events on the launch stream. */
 int rovmpc_timing_enable(rovmpc_handle *h, int32_t max_launches);
 int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t *count);

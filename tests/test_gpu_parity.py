@@ -516,10 +516,31 @@ def test_mpc_step_surface_and_closed_loop(rv):
     assert u.shape == (3,) and mpc.last.traj.shape == (21, 2) and np.isfinite(mpc.last.cost)
     u2 = mpc.step(rv.MPCState(P1=state[3:6], V1=state[6:9], theta=-0.03, gamma=-0.05))
     assert u2.shape == (3,)
-    from rovmpc.closed_loop import run_closed_loop
+    from rovmpc.closed_loop import run_closed_loop, closed_loop_inputs
     rep = run_closed_loop(mpc.engine, exp_case=12, n_steps=50)
     assert rep.steps == 50 and rep.u.shape == (50, 3) and np.isfinite(rep.cost).all()
     assert rep.real_time_factor > 0
+    # the device-side loop equals stepping by hand with the same plant rule (both modes)
+    import torch
+    eng = mpc.engine
+    rows, _ = closed_loop_inputs(eng, 12, 50)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    mean = torch.tensor(eng.model.mean[3:6], device="cuda"); scale = torch.tensor(eng.model.scale[3:6], device="cuda")
+    pools = (mean + scale * torch.randn((8, 512, 20, 3), generator=g, device="cuda", dtype=torch.float64)).cpu().numpy()
+    for fb in (False, True):
+        rep = run_closed_loop(eng, exp_case=12, n_steps=50, feedback=fb)
+        st = rows[0].copy()
+        for i in range(6):
+            if fb and i > 0:
+                st[0:12] = rows[i][0:12]
+            else:
+                st = rows[i].copy()
+            r = eng.step(st, pools[i % 8])
+            assert r.cost == rep.cost[i] and np.array_equal(r.u, rep.u[i])
+            np.testing.assert_array_equal(r.traj[1], rep.theta_gamma[i + 1])
+            if fb:
+                th, ga = st[12], st[13]
+                st = st.copy(); st[14], st[15] = th, ga; st[12], st[13] = r.traj[1]
     mpc.close()
 
 
