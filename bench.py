@@ -81,6 +81,7 @@ def main():
                     help="independent MPC steps in flight on one GPU (one engine handle + HIP stream each); 1 = strictly sequential steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pipelined-extra", action="store_true")
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
     ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows)")
     ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
@@ -124,7 +125,8 @@ def main():
     d_state = torch.tensor(state, device=dev)
     R = eng.result_len
     stream = torch.cuda.current_stream()
-    streams = [stream] if S == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # streams of different priority get different hardware queues (two same-priority streams can share one)
+    streams = [stream] if S == 1 else [torch.cuda.Stream(device=dev, priority=-(j % 2)) for j in range(S)]
     smpc = None
     collective = None
     if world > 1 or args.force_collective:
@@ -240,6 +242,28 @@ def main():
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 out["roofline"]["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
                 out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+        if world == 1 and smpc is None and S == 1 and not args.no_pipelined_extra:
+            # extra, not the headline: two independent MPC steps in flight on one GPU (second engine handle
+            # on a high-priority stream = its own hardware queue), so one step's launch ramp / arg-min tail
+            # overlaps the other's work
+            eng2 = rovmpc.Engine(cfg, model)
+            st2 = torch.cuda.Stream(device=dev, priority=-1)
+            pair = [(eng, stream), (eng2, st2)]
+            r2 = torch.empty((4, R), dtype=torch.float64, device=dev)
+            def step2(i):
+                e, st = pair[i & 1]
+                e.step_device(d_state.data_ptr(), pools[i % args.pools].data_ptr(), r2[i & 3].data_ptr(), st.cuda_stream)
+            for i in range(args.warmup):
+                step2(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                step2(i)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t2
+            out["two_steps_in_flight"] = {"value": units_per_step * args.steps / e2, "ms_per_step": 1e3 * e2 / args.steps,
+                                          "note": "throughput with 2 independent steps overlapped on one GPU; `value` above is 1 in flight"}
+            eng2.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.N)
         print(json.dumps(out))
