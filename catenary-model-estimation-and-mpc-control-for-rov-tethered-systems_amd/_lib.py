@@ -14,6 +14,7 @@ VT_NONE, VT_COMPOSE, VT_TABLE = 0, 1, 2
 PREV_INTERP, PREV_HOLD = 0, 1
 RK4, EULER, DOUBLE_EULER, TRAPEZOID = 0, 1, 2, 3
 ENU, NED = 0, 1
+FEATURES_GEN1, FEATURES_GEN2 = 0, 1
 STATE_LEN = 16
 
 ERR_NAMES = {0: "OK", -1: "ROVMPC_ERR_INVALID", -2: "ROVMPC_ERR_HIP", -3: "ROVMPC_ERR_NO_MODEL",
@@ -32,6 +33,7 @@ class Config(C.Structure):
         ("K", C.c_int32), ("n_shape_pts", C.c_int32), ("vt_mode", C.c_int32), ("prev_mode", C.c_int32),
         ("integrator", C.c_int32), ("frame", C.c_int32), ("force_interpreter", C.c_int32),
         ("candidates_per_block", C.c_int32), ("debug_flags", C.c_int32), ("jit_off", C.c_int32),
+        ("feature_map", C.c_int32), ("reserved1", C.c_int32),
         ("dt", C.c_double), ("v_scale", C.c_double), ("L", C.c_double), ("cable_wet_weight", C.c_double),
         ("c_lo", C.c_double), ("c_hi", C.c_double),
         ("w_theta", C.c_double), ("w_gamma", C.c_double), ("w_u", C.c_double), ("w_T", C.c_double),

@@ -57,7 +57,7 @@ template <typename T> struct RolloutArgs {
     double *blk_cost;         // [nblocks]
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
-    int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug;
+    int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
     // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
     unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
     double *result;               // [5 + 2(N+1)]
@@ -341,14 +341,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
             else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * kk.inv_h; Ay = (Vy - Wy) * kk.inv_h; Az = (Vz - Wz) * kk.inv_h; }
             const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
-            const T ap = m_clip((Vx * ux + Vy * uy + Vz * uz) / nv, T(-1), T(1));   // :31
+            T ap = (Vx * ux + Vy * uy + Vz * uz) / nv;
+            const int apslot = a.fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
+            if (a.fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
             RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
             RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
             RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
             RV_PL(sX, 6, n, c) = (Ax - sMean[6]) * sInv[6];
             RV_PL(sX, 7, n, c) = (Ay - sMean[7]) * sInv[7];
             RV_PL(sX, 8, n, c) = (Az - sMean[8]) * sInv[8];
-            RV_PL(sX, 13, n, c) = (ap - sMean[13]) * sInv[13];
+            RV_PL(sX, 13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
         }
     }
     __syncthreads();
@@ -581,20 +583,23 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
             const bool euler = a.integrator == ROVMPC_EULER;
             const T hstep = kk.h, inv_hstep = kk.inv_h;
+            const bool gen2 = a.fmap == ROVMPC_FEATURES_GEN2;
             const T hh = T(0.5) * hstep, h6 = hstep / T(6);
             // generic path: full 18-slot feature row per stage, bytecode interpreter
             T Vx = V0x, Vy = V0y, Vz = V0z;
             auto store_vslots = [&](int node, T vx, T vy, T vz, T ax, T ay, T az) {
                 const T ux = RV_PL(sA, 5, node, c), uy = RV_PL(sA, 6, node, c), uz = RV_PL(sA, 7, node, c);
                 const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
-                const T ap = m_clip((vx * ux + vy * uy + vz * uz) / nv, T(-1), T(1));
+                T ap = (vx * ux + vy * uy + vz * uz) / nv;
+                const int apslot = gen2 ? 16 : 13;
+                if (!gen2) ap = m_clip(ap, T(-1), T(1));
                 RV_PL(sX, 3, node, c) = (vx - sMean[3]) * sInv[3];
                 RV_PL(sX, 4, node, c) = (vy - sMean[4]) * sInv[4];
                 RV_PL(sX, 5, node, c) = (vz - sMean[5]) * sInv[5];
                 RV_PL(sX, 6, node, c) = (ax - sMean[6]) * sInv[6];
                 RV_PL(sX, 7, node, c) = (ay - sMean[7]) * sInv[7];
                 RV_PL(sX, 8, node, c) = (az - sMean[8]) * sInv[8];
-                RV_PL(sX, 13, node, c) = (ap - sMean[13]) * sInv[13];
+                RV_PL(sX, 13, node, c) = (ap - sMean[apslot]) * sInv[apslot];
             };
             if (VT == ROVMPC_VT_COMPOSE) store_vslots(0, Vx, Vy, Vz, A0x, A0y, A0z);
             T *feat = sF + c;                       // [slot][lane]
@@ -628,7 +633,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                             else if (cfrac2 == 2) x[s] = RV_PL(sX, s, n + 1, c);
                             else x[s] = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);   // :62
                         }
-                        x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
+                        if (gen2) {
+                            // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
+                            x[16] = x[13];                     // plane 13 carries angle_proj
+                            x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
+                            x[14] = (m_cos(yth) - m14) * i14; x[15] = (m_sin(yga) - m15) * i15;
+                            x[17] = T(0);
+                        } else {
+                            x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
+                        }
                         dth = jit_f_theta<T>(x);
                         dga = jit_f_gamma<T>(x);
                         return;
@@ -640,8 +653,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         else v = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);      // :62
                         feat[s * CK] = v;
                     }
-                    feat[14 * CK] = (yth - m14) * i14; feat[15 * CK] = (yga - m15) * i15;
-                    feat[16 * CK] = p16; feat[17 * CK] = p17;
+                    if (gen2) {
+                        feat[16 * CK] = feat[13 * CK];
+                        feat[12 * CK] = (yth - sMean[12]) * sInv[12]; feat[13 * CK] = (yga - sMean[13]) * sInv[13];
+                        feat[14 * CK] = (m_cos(yth) - m14) * i14; feat[15 * CK] = (m_sin(yga) - m15) * i15;
+                        feat[17 * CK] = T(0);
+                    } else {
+                        feat[14 * CK] = (yth - m14) * i14; feat[15 * CK] = (yga - m15) * i15;
+                        feat[16 * CK] = p16; feat[17 * CK] = p17;
+                    }
                     dth = interp_eval<T>(a.code_th, a.n_th, a.consts, feat, CK, stack, CK);
                     dga = interp_eval<T>(a.code_ga, a.n_ga, a.consts, feat, CK, stack, CK);
                 };

@@ -159,6 +159,7 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     if (cfg->prev_mode < 0 || cfg->prev_mode > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad prev_mode %d", cfg->prev_mode);
     if (cfg->integrator < 0 || cfg->integrator > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad integrator %d", cfg->integrator);
     if (cfg->frame < 0 || cfg->frame > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad frame %d", cfg->frame);
+    if (cfg->feature_map < 0 || cfg->feature_map > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad feature_map %d", cfg->feature_map);
     if (!(cfg->dt > 0) || !(cfg->L > 0) || !(cfg->c_lo > 0) || !(cfg->c_hi > cfg->c_lo))
         FAIL(nullh, ROVMPC_ERR_INVALID, "dt, L must be > 0 and 0 < c_lo < c_hi");
     if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64)
@@ -460,7 +461,7 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     }
     // Fingerprint against the compiled-in rows of saved_models/equations_*.csv
     // (complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3: x15 - x17).
-    bool same = n_features == 18 && !h->cfg.force_interpreter;
+    bool same = n_features == 18 && !h->cfg.force_interpreter && h->cfg.feature_map == ROVMPC_FEATURES_GEN1;
     if (same) {
         unsigned long long s = 0x9E3779B97F4A7C15ULL;
         for (int t = 0; t < 16 && same; ++t) {
@@ -480,7 +481,7 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
     h->jit_fn = nullptr;
     h->err.clear();
-    if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features == 18) {
+    if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features <= 18) {
         std::string why;
         const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
         hipFunction_t fn = jit_build(h->cfg.device, src, why);
@@ -523,7 +524,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
     a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
-    a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags;
+    a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags; a.fmap = c.feature_map;
     a.ticket = h->d_ticket;
     a.stamps = h->d_stamps;
 }
@@ -565,7 +566,10 @@ template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h,
 
 static int check_ready(rovmpc_handle *h) {
     if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
-    if (h->n_feat != 18) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the rollout kernel implements the 18-feature map of simply.py:15-41 (model has %d features)", h->n_feat);
+    const int want = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 17 : 18;
+    if (h->n_feat != want)
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "feature_map %d has %d slots (simply.py:15-41 / simulate_rk4_theta_gamma.py:12-42) but the model has %d",
+             h->cfg.feature_map, want, h->n_feat);
     if (h->cfg.vt_mode == ROVMPC_VT_TABLE && !h->has_rtab) FAIL(h, ROVMPC_ERR_INVALID, "vt_mode TABLE needs rovmpc_set_rotation_table");
     return ROVMPC_OK;
 }

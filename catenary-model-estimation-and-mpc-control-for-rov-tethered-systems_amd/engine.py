@@ -31,6 +31,7 @@ class MPCConfig:
     candidates_per_block: int = 0
     debug_flags: int = 0
     jit: bool = True             # specialise non-default models with hiprtc at set_model
+    feature_map: int = _lib.FEATURES_GEN1   # FEATURES_GEN2: 17 unscaled slots of simulate_rk4_theta_gamma.py:12-42
     dt: float = 1.0 / 60.0
     v_scale: float = 1e-3
     L: float = 3.0
@@ -65,6 +66,7 @@ class MPCConfig:
         c.candidates_per_block = self.candidates_per_block
         c.debug_flags = self.debug_flags
         c.jit_off = 0 if self.jit else 1
+        c.feature_map = self.feature_map
         for k in ("dt", "v_scale", "L", "cable_wet_weight", "c_lo", "c_hi", "w_theta", "w_gamma", "w_u", "w_T",
                   "w_taut", "rho_taut", "w_floor", "z_floor", "theta_ref", "gamma_ref"):
             setattr(c, k, float(getattr(self, k)))

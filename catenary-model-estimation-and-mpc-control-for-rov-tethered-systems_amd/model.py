@@ -101,3 +101,20 @@ def default_model(complexity_theta: Optional[int] = None, complexity_gamma: Opti
     return DynamicsModel(np.array(s["mean"]), np.array(s["scale"]),
                          select_row(e["dtheta_dt"]["rows"], ct)["sympy_format"],
                          select_row(e["dgamma_dt"]["rows"], cg)["sympy_format"])
+
+
+def generation2_model(complexity_theta: Optional[int] = None, complexity_gamma: Optional[int] = None) -> DynamicsModel:
+    """Generation-2 model of the reference (what simulate_rk4_theta_gamma.py:45-46 loads): 17 UNSCALED
+    features [P1, V1, A1, unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
+    (simulate_rk4_theta_gamma.py:40), rows of outputs/differential_training_new_feature/
+    d{theta,gamma}_results_20250412_163500.csv named by eq_*_20250412_163500.txt:1 (complexity 13 / 20).
+    Use with ``MPCConfig(feature_map=FEATURES_GEN2)``."""
+    e = json.load(open(os.path.join(DATA_DIR, "gen2_equations.json")))
+    ct = complexity_theta or e["dtheta_dt"]["chosen_complexity"]
+    cg = complexity_gamma or e["dgamma_dt"]["chosen_complexity"]
+    m = DynamicsModel.__new__(DynamicsModel)
+    m.mean = np.zeros(17); m.scale = np.ones(17)
+    m.expr_theta = select_row(e["dtheta_dt"]["rows"], ct)["sympy_format"]
+    m.expr_gamma = select_row(e["dgamma_dt"]["rows"], cg)["sympy_format"]
+    m.__post_init__()
+    return m

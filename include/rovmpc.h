@@ -64,6 +64,14 @@ extern "C" {
 #define ROVMPC_ENU 0
 #define ROVMPC_NED 1
 
+/* Feature map the loaded expressions are written over:
+ * GEN1: 18 slots [P1, V1, A1, unit_rel, tension, angle_proj, theta, gamma, theta_prev, gamma_prev],
+ *       StandardScaler-normalised (simply.py:15-41, saved_models/);
+ * GEN2: 17 slots [P1, V1, A1, unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj(unclipped)],
+ *       unscaled (simulate_rk4_theta_gamma.py:12-42, outputs/differential_training_new_feature/). */
+#define ROVMPC_FEATURES_GEN1 0
+#define ROVMPC_FEATURES_GEN2 1
+
 #define ROVMPC_MAX_FEATURES 32
 #define ROVMPC_MAX_CODE     256
 #define ROVMPC_MAX_STACK    16
@@ -100,6 +108,8 @@ typedef struct rovmpc_config {
     int32_t candidates_per_block; /* 0 = auto; else 1..64                                   */
     int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
     int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
+    int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | ROVMPC_FEATURES_GEN2              */
+    int32_t reserved1;
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
     double L;                   /* cable length [m] (test_cluster.py:22)                    */

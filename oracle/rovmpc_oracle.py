@@ -439,6 +439,7 @@ class MPCConfig:
     theta_ref: float = 0.0
     gamma_ref: float = 0.0
     U_ref: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    feature_map: int = 0             # 0: 18 scaled slots (simply.py:15-41); 1: 17 unscaled slots (simulate_rk4_theta_gamma.py:12-42)
 
 
 @dataclass
@@ -472,14 +473,18 @@ class DynamicsModel:
     f_gamma: SymbolicModel
 
 
-def _exo_features_scalar(P0, P, V, A, mean, scale):
-    """simply.py:25-31 for one row; returns the 14 scaled exogenous slots."""
+def _exo_features_scalar(P0, P, V, A, mean, scale, fmap=0):
+    """simply.py:25-31 for one row; returns the 14 scaled exogenous slots (generation 2,
+    simulate_rk4_theta_gamma.py:25-38: slot 12 unused, slot 13 = UNCLIPPED angle_proj scaled as x16)."""
     rel = P - P0
     nr = np.linalg.norm(rel)
     unit_rel = rel / (nr + 1e-8)
     tension = np.clip(nr, 1e-5, 10)
-    angle_proj = np.clip(np.dot(V, unit_rel) / (np.linalg.norm(V) + 1e-8), -1, 1)
-    x = np.concatenate([P, V, A, unit_rel, [tension, angle_proj]])
+    angle_proj = np.dot(V, unit_rel) / (np.linalg.norm(V) + 1e-8)
+    if fmap == 1:
+        x = np.concatenate([P, V, A, unit_rel])
+        return np.concatenate([(x - mean[:12]) / scale[:12], [0.0, (angle_proj - mean[16]) / scale[16]]])
+    x = np.concatenate([P, V, A, unit_rel, [tension, np.clip(angle_proj, -1, 1)]])
     return (x - mean[:14]) / scale[:14]
 
 
@@ -509,7 +514,7 @@ def rollout_scalar(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rta
         A = np.asarray(state.A1, float).copy()
         th, ga, thm, gam = state.theta, state.gamma, state.theta_prev, state.gamma_prev
         traj[k, 0] = (th, ga)
-        xs_n = _exo_features_scalar(P0, P, V, A, mean, scale)
+        xs_n = _exo_features_scalar(P0, P, V, A, mean, scale, cfg.feature_map)
         Jk = 0.0
         for n in range(N):
             Uw = U[k, n]
@@ -521,7 +526,7 @@ def rollout_scalar(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rta
                 Vn = np.asarray(Rtab[n], float).reshape(3, 3) @ Uw
             Pn = P + (cfg.v_scale * h) * Uw
             An = (Vn - V) / h
-            xs_n1 = _exo_features_scalar(P0, Pn, Vn, An, mean, scale)
+            xs_n1 = _exo_features_scalar(P0, Pn, Vn, An, mean, scale, cfg.feature_map)
 
             def stage(yth, yga, c):
                 if c == 0.0:
@@ -530,6 +535,11 @@ def rollout_scalar(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rta
                     exo = xs_n1
                 else:
                     exo = (xs_n + xs_n1) / 2                      # :62 feature midpoint
+                if cfg.feature_map == 1:        # simulate_rk4_theta_gamma.py:40
+                    row = np.concatenate([exo[:12], [(yth - mean[12]) / scale[12], (yga - mean[13]) / scale[13],
+                                                     (np.cos(yth) - mean[14]) / scale[14],
+                                                     (np.sin(yga) - mean[15]) / scale[15], exo[13]]])
+                    return f(row)
                 s16a = (thm - mean[16]) / scale[16]; s16b = (th - mean[16]) / scale[16]
                 s17a = (gam - mean[17]) / scale[17]; s17b = (ga - mean[17]) / scale[17]
                 if cfg.prev_mode == 1 or c == 0.0:
@@ -601,15 +611,17 @@ def _axes_vec(rel):
     return th, ga
 
 
-def _exo_features_vec(P0, P, V, A, mean, scale):
+def _exo_features_vec(P0, P, V, A, mean, scale, fmap=0):
     rel = P - P0
     nr = np.linalg.norm(rel, axis=1, keepdims=True)
     unit_rel = rel / (nr + 1e-8)
     tension = np.clip(nr, 1e-5, 10)
     with np.errstate(all="ignore"):
-        angle_proj = np.clip(np.sum(V * unit_rel, axis=1, keepdims=True)
-                             / (np.linalg.norm(V, axis=1, keepdims=True) + 1e-8), -1, 1)
-    x = np.hstack([P, V, A, unit_rel, tension, angle_proj])
+        angle_proj = np.sum(V * unit_rel, axis=1, keepdims=True) / (np.linalg.norm(V, axis=1, keepdims=True) + 1e-8)
+    if fmap == 1:
+        x = np.hstack([P, V, A, unit_rel])
+        return np.hstack([(x - mean[:12]) / scale[:12], np.zeros_like(nr), (angle_proj - mean[16]) / scale[16]])
+    x = np.hstack([P, V, A, unit_rel, tension, np.clip(angle_proj, -1, 1)])
     return (x - mean[:14]) / scale[:14]
 
 
@@ -661,7 +673,9 @@ def rollout_vec(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=N
     traj = np.zeros((K, N + 1, 2)); traj[:, 0, 0] = th; traj[:, 0, 1] = ga
     J = np.zeros(K)
     Tn = np.zeros((K, N)); Zn = np.zeros((K, N)); Cn = np.zeros((K, N))
-    xs_n = _exo_features_vec(P0, P, V, A, mean, scale)
+    xs_n = _exo_features_vec(P0, P, V, A, mean, scale, cfg.feature_map)
+    if cfg.feature_map == 1:
+        s16a = s16b = s17a = s17b = None
 
     def f(cols):
         a = np.broadcast_to(np.asarray(model.f_theta(cols), float), (K,))
@@ -680,9 +694,10 @@ def rollout_vec(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=N
                 Vn = Uw @ np.asarray(Rtab[n], float).reshape(3, 3).T
             Pn = P + (cfg.v_scale * h) * Uw
             An = (Vn - V) / h
-            xs_n1 = _exo_features_vec(P0, Pn, Vn, An, mean, scale)
-            s16a = (thm - mean[16]) / scale[16]; s16b = (th - mean[16]) / scale[16]
-            s17a = (gam - mean[17]) / scale[17]; s17b = (ga - mean[17]) / scale[17]
+            xs_n1 = _exo_features_vec(P0, Pn, Vn, An, mean, scale, cfg.feature_map)
+            if cfg.feature_map != 1:
+                s16a = (thm - mean[16]) / scale[16]; s16b = (th - mean[16]) / scale[16]
+                s17a = (gam - mean[17]) / scale[17]; s17b = (ga - mean[17]) / scale[17]
 
             def stage(yth, yga, c):
                 if c == 0.0:
@@ -691,6 +706,11 @@ def rollout_vec(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=N
                     exo = xs_n1
                 else:
                     exo = (xs_n + xs_n1) / 2
+                if cfg.feature_map == 1:
+                    cols = [exo[:, i] for i in range(12)]
+                    cols += [(yth - mean[12]) / scale[12], (yga - mean[13]) / scale[13],
+                             (np.cos(yth) - mean[14]) / scale[14], (np.sin(yga) - mean[15]) / scale[15], exo[:, 13]]
+                    return f(cols)
                 if cfg.prev_mode == 1 or c == 0.0:
                     p16, p17 = s16a, s17a
                 elif c == 1.0:

@@ -33,7 +33,8 @@ def oracle_cfg(orc, cfg):
                          up=1.0 if cfg.frame == "ENU" else -1.0, vt_mode=cfg.vt_mode, prev_mode=cfg.prev_mode,
                          integrator=cfg.integrator, w_theta=cfg.w_theta, w_gamma=cfg.w_gamma, w_u=cfg.w_u,
                          w_T=cfg.w_T, w_taut=cfg.w_taut, rho_taut=cfg.rho_taut, w_floor=cfg.w_floor,
-                         z_floor=cfg.z_floor, theta_ref=cfg.theta_ref, gamma_ref=cfg.gamma_ref, U_ref=tuple(cfg.U_ref))
+                         z_floor=cfg.z_floor, theta_ref=cfg.theta_ref, gamma_ref=cfg.gamma_ref, U_ref=tuple(cfg.U_ref),
+                         feature_map=cfg.feature_map)
 
 
 def oracle_model(orc, model):
@@ -328,6 +329,24 @@ def test_jit_specialisation_modes(rv, orc, vt_mode, prev_mode, integrator, dtype
                 R20 = rand_rtab(20); ej.set_rotation_table(R20); eb.set_rotation_table(R20)
             assert eb.model_path == "builtin"
             np.testing.assert_allclose(ej.rollout_costs(state, U), eb.rollout_costs(state, U), rtol=1e-11)
+
+
+@pytest.mark.parametrize("jit", [True, False])
+@pytest.mark.parametrize("vt_mode", [0, 1])
+def test_generation2_feature_map(rv, orc, jit, vt_mode):
+    """The model simulate_rk4_theta_gamma.py actually loads: 17 unscaled features incl. cos(theta),
+    sin(gamma) and the unclipped angle_proj; rows 13 / 20 of outputs/differential_training_new_feature/."""
+    model = rv.generation2_model()
+    cfg = rv.MPCConfig(N=10, K=72, feature_map=rv.FEATURES_GEN2, jit=jit, vt_mode=vt_mode)
+    with rv.Engine(cfg, model) as e:
+        assert e.model_path == ("jit" if jit else "interpreter")
+    (J, traj, res), (Jo, trajo, _), (state, U) = run_both(rv, orc, cfg, model)
+    np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-8)
+    assert res.index == int(np.argmin(Jo))
+    with pytest.raises(rv.RovmpcError):                       # 17-slot model on the 18-slot map
+        with rv.Engine(rv.MPCConfig(N=4, K=8), model) as e:
+            e.step(state, U[:8, :4])
 
 
 def test_rollout_c3_fp32(rv, orc):

@@ -231,3 +231,29 @@ def test_kabsch_rotation(golden_dir):
         assert np.linalg.det(R) == pytest.approx(1.0, abs=1e-12)
     v, R = orc.kabsch_velocity_transform(g["P"], g["Q"], g["v"])
     np.testing.assert_allclose(v, g["v_out"], rtol=1e-11, atol=1e-11)
+
+
+def test_generation2_equations(golden_dir):
+    import json
+    eq = json.load(open(os.path.join(golden_dir, "equations_gen2.json")))
+    assert eq["dtheta_dt"]["chosen_complexity"] == 13 and eq["dgamma_dt"]["chosen_complexity"] == 20
+    g = np.load(os.path.join(golden_dir, "kat_dynamics_gen2.npz"))
+    for which, key in (("dtheta_dt", "out_theta"), ("dgamma_dt", "out_gamma")):
+        for i, row in enumerate(eq[which]["rows"]):
+            got = orc.SymbolicModel(row["sympy_format"], 17).predict(g["X"])
+            np.testing.assert_allclose(got, g[key][i], rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
+def test_generation2_scalar_and_vector_rollouts_agree(golden_dir):
+    import json
+    eq = json.load(open(os.path.join(golden_dir, "equations_gen2.json")))
+    row = lambda w: [r for r in eq[w]["rows"] if r["complexity"] == eq[w]["chosen_complexity"]][0]["sympy_format"]
+    model = orc.DynamicsModel(np.zeros(17), np.ones(17), orc.SymbolicModel(row("dtheta_dt"), 17), orc.SymbolicModel(row("dgamma_dt"), 17))
+    cfg = orc.MPCConfig(N=6, n_shape_pts=6, feature_map=1)
+    rng = np.random.default_rng(3)
+    st = orc.MPCState(np.zeros(3), np.array([0.24, -0.76, 0.3]), np.array([80., -20., -18.]), np.zeros(3), -0.03, -0.05, -0.03, -0.05)
+    U = np.array([80., -20., -18.]) + np.array([100., 15., 60.]) * rng.standard_normal((10, 6, 3))
+    Js, ts, _ = orc.rollout_scalar(cfg, model, st, U)
+    Jv, tv, _ = orc.rollout_vec(cfg, model, st, U)
+    np.testing.assert_allclose(tv, ts, rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(Jv, Js, rtol=1e-10)

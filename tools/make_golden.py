@@ -271,6 +271,27 @@ def main():
     for c in (1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14):
         shutil.copyfile(f"{REF}/Results/Trajectory Data/rov_trajectory_exp{c}.csv",
                         f"{OUT}/rov_trajectory_exp{c}.csv")
+    rng2 = np.random.default_rng(2)          # own stream: keeps sections 1-9 reproducible
+    # 10. generation-2 equations (outputs/differential_training_new_feature/, 17 unscaled features)
+    g2 = {}
+    for which, fn in (("dtheta_dt", "dtheta_results_20250412_163500.csv"), ("dgamma_dt", "dgamma_results_20250412_163500.csv")):
+        rows = []
+        with open(f"{REF}/outputs/differential_training_new_feature/{fn}") as f:
+            for r in csv.DictReader(f):
+                rows.append({"complexity": int(r["complexity"]), "loss": float(r["loss"]), "score": float(r["score"]),
+                             "equation": r["equation"], "sympy_format": r["sympy_format"]})
+        txt = open(f"{REF}/outputs/differential_training_new_feature/eq_{which}_20250412_163500.txt").read()
+        g2[which] = {"chosen_complexity": int(txt.split("\n")[0].split()[-1]), "rows": rows}
+    json.dump(g2, open(f"{OUT}/equations_gen2.json", "w"), indent=1)
+    X2 = np.hstack([rng2.normal(0, 1, (128, 3)), rng2.normal(0, 100, (128, 3)), rng2.normal(0, 300, (128, 3)),
+                    rng2.normal(0, 0.6, (128, 3)), rng2.normal(0, 0.1, (128, 2)), rng2.uniform(-1, 1, (128, 3))])
+    f2t = lambdify_rows(g2["dtheta_dt"]["rows"], 17); f2g = lambdify_rows(g2["dgamma_dt"]["rows"], 17)
+    c2 = [X2[:, i] for i in range(17)]
+    with np.errstate(all="ignore"):
+        o2t = np.stack([np.broadcast_to(np.asarray(f(*c2), float), (128,)) for f in f2t])
+        o2g = np.stack([np.broadcast_to(np.asarray(f(*c2), float), (128,)) for f in f2g])
+    np.savez(f"{OUT}/kat_dynamics_gen2.npz", X=X2, out_theta=o2t, out_gamma=o2g)
+
     print("golden vectors written to", OUT)
 
 
