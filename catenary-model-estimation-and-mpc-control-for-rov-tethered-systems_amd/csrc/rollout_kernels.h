@@ -265,7 +265,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
         }
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
-        if (tid == 0) *s_prog = 0;
+        if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; }
 
     }
     // state (uniform loads)
@@ -362,8 +362,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // phase 4a, item (n, c): node n+1 of candidate c.  Nothing here depends on (theta, gamma):
     // catenary parameter + tension of the straight geometry (main_fun.py:292-293, 303-305),
     // tautness and control terms of the cost.
-    auto geometry_a = [&](int first, int stride) {
-        for (int i = first; i < ((a.debug & 2) ? 0 : N * CK); i += stride) {
+    auto geometry_a = [&](int first, int stride, int begin) {
+        for (int i = begin + first; i < ((a.debug & 2) ? 0 : N * CK); i += stride) {
             const int n = i / CK, c = i % CK;
             const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                     rz = RV_PL(sP, 2, n + 1, c) - P0z;
@@ -396,6 +396,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
         sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);
     };
+    // items taken through phase 4b early (compiled-in model, one theta wave, at least one pure geometry wave)
+    int early = 0;
+    if (MODEL == MODEL_BUILTIN && CK <= 16 && NT >= 64 + 64 + 64 && N * CK > 256) {
+        const int r = (N * CK) % 256;
+        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
+    }
     // Measured and rejected: letting the geometry waves chase the integrating wave node by node
     // (LDS progress flags) -- a phase-4b item is a ~4 us dependent chain whatever the lane count, so
     // the tail after the last integration step does not shrink and the extra waves slow the
@@ -546,7 +552,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 thm = th; th = thn;
                 x3a = x3b; sinXa = sinXb;
                 if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = gan; }
+                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
 
         if (NT >= nint + 64) {
@@ -559,15 +567,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 __builtin_amdgcn_s_setprio(2);
                 gamma_path();
                 __builtin_amdgcn_s_setprio(0);
-                geometry_a(tid - nint, NT - nint);
+                geometry_a(tid - nint, NT - nint, early);
             } else {
-                geometry_a(tid - nint, NT - nint);
+                // Early batch: N*CK items on a workgroup of N*CK threads are one wave more than the
+                // CU has SIMDs (320 items = 5 waves on 4 SIMDs: one SIMD would issue two waves' worth
+                // of phase 4b after the join).  The first `early` items -- the nodes the theta wave
+                // finishes first -- are therefore taken through 4a AND 4b by an otherwise idle wave
+                // while the integration is still running; the join then leaves a multiple of 256.
+                const int j = tid - nint - 64;
+                if (j < early && !(a.debug & 2)) geometry_a(j, 1 << 30, 0);
+                geometry_a(tid - nint, NT - nint, early);
+                if (j < early && !(a.debug & 2)) {
+                    const int n = j / CK;
+                    while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
+                    geometry_b_item(n, j % CK);
+                }
             }
         } else {
             if (tid < 64) gamma_path();              // tiny workgroups: gamma path first, same wave
             __syncthreads();
             if (tid < nint) theta_path();
-            geometry_a(tid, NT);
+            geometry_a(tid, NT, 0);
         }
     } else {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
@@ -687,18 +707,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (tid < nint) {
                 integrate();
             } else {
-                geometry_a(tid - nint, NT - nint);
+                geometry_a(tid - nint, NT - nint, 0);
             }
         } else {
             integrate();
-            geometry_a(tid, NT);
+            geometry_a(tid, NT, 0);
         }
     }
     __syncthreads();
 
     RV_STAMP(4);
     // ---- phase 4b ---------------------------------------------------------------------------
-    for (int i = tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) geometry_b_item(i / CK, i % CK);
+    for (int i = early + tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) geometry_b_item(i / CK, i % CK);
     __syncthreads();
 
     RV_STAMP(5);
