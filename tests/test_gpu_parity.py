@@ -378,6 +378,21 @@ def test_ragged_and_tiny_shapes(rv, orc, K, N, ck):
     assert res.index == int(np.argmin(Jo))
 
 
+@pytest.mark.parametrize("N,K,ck,vt,prev,integ", [(36, 64, 0, 1, 0, 0), (40, 40, 8, 1, 1, 0), (21, 48, 16, 0, 0, 0),
+                                                   (24, 32, 0, 2, 0, 1), (33, 200, 0, 1, 0, 0), (17, 96, 4, 1, 0, 0),
+                                                   (64, 64, 0, 1, 0, 0), (20, 8192, 0, 1, 0, 0)])
+def test_workgroup_shapes_of_the_compiled_in_path(rv, orc, N, K, ck, vt, prev, integ):
+    """Shapes that exercise every dispatch of the compiled-in kernel: early phase-4b batch with one
+    and with several post-join rounds, no early batch, several theta waves (32 candidates per
+    workgroup), tiny workgroups, Euler and HOLD."""
+    cfg = rv.MPCConfig(N=N, K=K, candidates_per_block=ck, vt_mode=vt, prev_mode=prev, integrator=integ, n_shape_pts=7)
+    Rtab = rand_rtab(N) if vt == 2 else None
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg, Rtab=Rtab)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    assert res.index == int(np.argmin(Jo))
+
+
 def test_geometry_edge_cases_in_rollout(rv, orc):
     """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
     a vertical cable (degenerate xy projection)."""
