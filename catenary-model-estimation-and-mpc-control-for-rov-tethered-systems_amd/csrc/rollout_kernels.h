@@ -195,7 +195,7 @@ __host__ __device__ inline int rollout_nx(int model, int vt) {
     return model == MODEL_BUILTIN ? (vt == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
 }
 __host__ __device__ inline int rollout_na(int model, int vt) {
-    return vt == ROVMPC_VT_COMPOSE ? (model == MODEL_BUILTIN ? 5 : NAX) : 5;   // axes are reused by phase 4b
+    return vt == ROVMPC_VT_COMPOSE ? NAX : 5;   // axes are reused by phase 4b; compose: + 3 (unit_rel, or w of the compiled-in path)
 }
 constexpr int HDR = 48;            // header: flags (8 slots) + mean[18] + inv_scale[18] (+ pad)
 
@@ -220,7 +220,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int k0 = blockIdx.x * CK;
     const int nvalid = min(CK, K - k0);
     constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
-    constexpr int NA = VT == ROVMPC_VT_COMPOSE ? (MODEL == MODEL_BUILTIN ? 5 : NAX) : 5;
+    constexpr int NA = VT == ROVMPC_VT_COMPOSE ? NAX : 5;
 
     // carve LDS
     int *s_best_c = reinterpret_cast<int *>(smem);   // header
@@ -456,11 +456,26 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);     // :66
                 }
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    // first half of the velocity transform, w = R_gamma(-gamma_n) u_n: it needs gamma_n
+                    // only, so it leaves the theta waves' chain; lane (quad q, role 0) serves candidates
+                    // q, q + 16, ...
+                    if ((tid & 3) == 0) {
+                        for (int cq = (tid & 63) >> 2; cq < CK; cq += 16) {
+                            const V3<T> kg = {RV_PL(sA, 2, n, cq), RV_PL(sA, 3, n, cq), RV_PL(sA, 4, n, cq)};
+                            const T *u = &sU[cq * US + n * 3];
+                            const V3<T> w = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sr[1], cr4[1]);
+                            RV_PL(sA, 5, n, cq) = w.x; RV_PL(sA, 6, n, cq) = w.y; RV_PL(sA, 7, n, cq) = w.z;
+                        }
+                    }
+                }
                 if ((tid & 63) == 0) {
                     T *g = sG + 8 * n;
                     g[0] = sr[1]; g[1] = cr4[1]; g[2] = sinA; g[3] = sinM; g[4] = sinE; g[5] = gan;
-                    __hip_atomic_store(s_prog, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                // every lane's w stores precede this wave's release (DS operations complete in order)
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+                if ((tid & 63) == 0) __hip_atomic_store(s_prog, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 gam = ga; ga = gan; s17a = s17b; sinA = sinB;
             }
             if ((tid & 63) == 0) __hip_atomic_store(s_prog, N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -480,13 +495,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T x3a = (V0x - m3) * i3;
             T sinXa = trig.sin(x3a);
             // operands of the velocity transform of step 0 (prefetched one step ahead below)
-            T ktx = T(0), kty = T(0), kgx = T(0), kgy = T(0), kgz = T(0), u0 = T(0), u1 = T(0), u2 = T(0), x3n = T(0);
+            T ktx = T(0), kty = T(0), x3n = T(0);
             auto fetch = [&](int n) {
                 if (VT == ROVMPC_VT_COMPOSE) {
                     ktx = RV_PL(sA, 0, n, c); kty = RV_PL(sA, 1, n, c);
-                    kgx = RV_PL(sA, 2, n, c); kgy = RV_PL(sA, 3, n, c); kgz = RV_PL(sA, 4, n, c);
-                    const T *u = &sU[c * US + n * 3];
-                    u0 = u[0]; u1 = u[1]; u2 = u[2];
                 } else {
                     x3n = RV_PL(sX, 0, n + 1, c);
                 }
@@ -504,16 +516,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
                 while (__hip_atomic_load(s_prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n) __builtin_amdgcn_s_sleep(1);
                 const T *g = sG + 8 * n;
-                const T sg = g[0], cg = g[1], sinA = g[2], sinM = g[3], sinE = g[4], gan = g[5];
+                const T sinA = g[2], sinM = g[3], sinE = g[4], gan = g[5];
                 T x3b;
                 if (VT == ROVMPC_VT_COMPOSE) {
                     // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world with the
                     // cable axes at node n (R @ v of velocity_transform_batch.py:100-101, R composed
-                    // from the augmentation angles); only its x component feeds x3
+                    // from the augmentation angles); w = R_gamma(-gamma_n) v_world comes from the gamma
+                    // wave, and only the x component of R_theta w feeds x3
                     const V3<T> kt = {ktx, kty, T(0)};
-                    const V3<T> kg = {kgx, kgy, kgz};
-                    V3<T> v = rodrigues_unit<T>({u0, u1, u2}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    const V3<T> w = {RV_PL(sA, 5, n, c), RV_PL(sA, 6, n, c), RV_PL(sA, 7, n, c)};
+                    const V3<T> v = rodrigues_unit<T>(w, kt, st, ct);
                     x3b = (v.x - m3) * i3;
                 } else {
                     x3b = x3n;
