@@ -58,6 +58,8 @@ template <typename T> struct RolloutArgs {
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
+    int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
+    unsigned magic_3n;            // floor(2^32 / (3N)) + 1: g / (3N) == umulhi(g, magic) for g < 2^16
     // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
     unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
     double *result;               // [5 + 2(N+1)]
@@ -215,6 +217,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
     const int N = a.N, CK = a.CK, K = a.K;
+    const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const RolloutConsts<T> &kk = *a.k;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int k0 = blockIdx.x * CK;
@@ -250,17 +253,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 const vecT v = src4[i];
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
-                    const int g = i * VW + e, c = g / (3 * N), j = g - c * (3 * N);
+                    const int g = i * VW + e, c = (int)__umulhi((unsigned)g, a.magic_3n), j = g - c * (3 * N);
                     sU[c * US + j] = v[e];
                 }
             }
             for (int i = tot + tid; i < CK * N * 3; i += NT) {
-                const int c = i / (3 * N), j = i - c * (3 * N);
+                const int c = (int)__umulhi((unsigned)i, a.magic_3n), j = i - c * (3 * N);
                 sU[c * US + j] = T(0);
             }
         } else {
             for (int i = tid; i < CK * N * 3; i += NT) {
-                const int c = i / (3 * N), j = i - c * (3 * N);
+                const int c = (int)__umulhi((unsigned)i, a.magic_3n), j = i - c * (3 * N);
                 sU[c * US + j] = (i < tot) ? src[i] : T(0);
             }
         }
@@ -292,7 +295,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     };
     for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
         // far nodes first: with N*CK threads the one leftover round is then node 0 (no sum at all)
-        const int n = N - i / CK, c = i % CK;
+        const int n = N - (i >> cks), c = i & ckm;
         // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
         // sequential order by the item itself (independent LDS reads, no scan, no extra barrier)
         T Px = (T)sd[3], Py = (T)sd[4], Pz = (T)sd[5];
@@ -364,7 +367,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // tautness and control terms of the cost.
     auto geometry_a = [&](int first, int stride, int begin) {
         for (int i = begin + first; i < ((a.debug & 2) ? 0 : N * CK); i += stride) {
-            const int n = i / CK, c = i % CK;
+            const int n = i >> cks, c = i & ckm;
             const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                     rz = RV_PL(sP, 2, n + 1, c) - P0z;
             const T *u = &sU[c * US + n * 3];
@@ -590,9 +593,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (j < early && !(a.debug & 2)) geometry_a(j, 1 << 30, 0);
                 geometry_a(tid - nint, NT - nint, early);
                 if (j < early && !(a.debug & 2)) {
-                    const int n = j / CK;
+                    const int n = j >> cks;
                     while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
-                    geometry_b_item(n, j % CK);
+                    geometry_b_item(n, j & ckm);
                 }
             }
         } else {
@@ -730,7 +733,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 
     RV_STAMP(4);
     // ---- phase 4b ---------------------------------------------------------------------------
-    for (int i = early + tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) geometry_b_item(i / CK, i % CK);
+    for (int i = early + tid; i < ((a.debug & 2) ? 0 : N * CK); i += NT) geometry_b_item(i >> cks, i & ckm);
     __syncthreads();
 
     RV_STAMP(5);

@@ -162,8 +162,10 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     if (cfg->feature_map < 0 || cfg->feature_map > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad feature_map %d", cfg->feature_map);
     if (!(cfg->dt > 0) || !(cfg->L > 0) || !(cfg->c_lo > 0) || !(cfg->c_hi > cfg->c_lo))
         FAIL(nullh, ROVMPC_ERR_INVALID, "dt, L must be > 0 and 0 < c_lo < c_hi");
-    if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64)
-        FAIL(nullh, ROVMPC_ERR_INVALID, "candidates_per_block must be 0..64");
+    if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64 ||
+        (cfg->candidates_per_block & (cfg->candidates_per_block - 1)) != 0)
+        FAIL(nullh, ROVMPC_ERR_INVALID, "candidates_per_block must be 0 (auto) or a power of two <= 64");
+    if ((long long)cfg->N * 3 * 64 >= 65536) FAIL(nullh, ROVMPC_ERR_INVALID, "N must be below 341 (LDS-resident horizon)");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -525,6 +527,9 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
     a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags; a.fmap = c.feature_map;
+    a.ck_shift = 0;
+    while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
+    a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
     a.ticket = h->d_ticket;
     a.stamps = h->d_stamps;
 }

@@ -105,7 +105,7 @@ typedef struct rovmpc_config {
     int32_t integrator;         /* ROVMPC_RK4 | ROVMPC_EULER                                */
     int32_t frame;              /* ROVMPC_ENU | ROVMPC_NED (catenary.py:10)                 */
     int32_t force_interpreter;  /* 1: never take the compiled-in default-equation path      */
-    int32_t candidates_per_block; /* 0 = auto; else 1..64                                   */
+    int32_t candidates_per_block; /* 0 = auto; else a power of two <= 64                    */
     int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
     int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
     int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | ROVMPC_FEATURES_GEN2              */
