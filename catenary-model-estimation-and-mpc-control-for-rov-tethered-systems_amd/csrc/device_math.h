@@ -377,6 +377,19 @@ RV_DEV void quad4(float v, float (&out)[4]) {
     out[2] = __uint_as_float(quad_bcast_u32<2>(u)); out[3] = __uint_as_float(quad_bcast_u32<3>(u));
 }
 
+// Lane i of a 16-lane row reads lane i + SH of the same row (lanes without a source keep their
+// own value): v_mov_b32_dpp row_shl.  Used for the arg-min over <= 16 candidates of a workgroup.
+template <int SH> RV_DEV unsigned row_shl_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x100 + SH, 0xf, 0xf, false);
+}
+template <int SH> RV_DEV double row_shl(double v) {
+    return __hiloint2double((int)row_shl_u32<SH>((unsigned)__double2hiint(v)), (int)row_shl_u32<SH>((unsigned)__double2loint(v)));
+}
+template <int SH> RV_DEV long long row_shl(long long v) {
+    const unsigned lo = row_shl_u32<SH>((unsigned)v), hi = row_shl_u32<SH>((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // order-preserving double <-> int64 map (signed compare of keys == IEEE compare of values)
 RV_DEV long long ordered_key(double v) {
     long long b = __double_as_longlong(v);

@@ -754,11 +754,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             a.J[k0 + c] = J;
             Jd = (double)J; kk = k0 + c;
         }
-        // wave arg-min, lowest index on ties (np.argmin)
-        for (int off = 32; off > 0; off >>= 1) {
-            const double oJ = __shfl_down(Jd, off, 64);
-            const long long ok = __shfl_down(kk, off, 64);
-            if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
+        // wave arg-min, lowest index on ties (np.argmin): DPP row shifts when the candidates fit one
+        // 16-lane row, ds_bpermute shuffles otherwise
+        auto take = [&](double oJ, long long ok) { if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; } };
+        if (CK <= 16) {
+            take(row_shl<8>(Jd), row_shl<8>(kk));
+            take(row_shl<4>(Jd), row_shl<4>(kk));
+            take(row_shl<2>(Jd), row_shl<2>(kk));
+            take(row_shl<1>(Jd), row_shl<1>(kk));
+        } else {
+            for (int off = 32; off > 0; off >>= 1) take(__shfl_down(Jd, off, 64), __shfl_down(kk, off, 64));
         }
         if (c == 0) {
             st_agent(&a.blk_cost[blockIdx.x], Jd);
