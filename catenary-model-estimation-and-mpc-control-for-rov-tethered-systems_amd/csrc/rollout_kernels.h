@@ -27,6 +27,12 @@ constexpr int MODEL_BUILTIN = 0;   // saved_models/eq_*.txt rows (complexity 13 
 constexpr int MODEL_INTERP  = 1;   // any bytecode
 constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compiled with hiprtc at set_model
 
+// Exogenous planes (0..13) the loaded expressions read.  A run-time argument for the interpreter;
+// the run-time generated translation unit defines it as a literal, so unused planes vanish there.
+#ifndef ROVMPC_JIT_USED
+#define ROVMPC_JIT_USED 0xffffffffu
+#endif
+
 // Defined by the run-time generated translation unit (MODEL_JIT only): the two expressions
 // over the 18 scaled feature values of one stage.
 template <typename T> __device__ T jit_f_theta(const T *x);
@@ -59,6 +65,7 @@ template <typename T> struct RolloutArgs {
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
+    unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
     unsigned magic_3n;            // floor(2^32 / (3N)) + 1: g / (3N) == umulhi(g, magic) for g < 2^16
     // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
     unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
@@ -218,6 +225,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *smem = reinterpret_cast<T *>(smem_raw);
     const int N = a.N, CK = a.CK, K = a.K;
     const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
+    const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
+    auto uses = [&](int plane) { return (used >> plane) & 1u; };
     const RolloutConsts<T> &kk = *a.k;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int k0 = blockIdx.x * CK;
@@ -327,13 +336,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T inr = T(1) / (nr + T(1e-8));                                 // :26
         const T ux = rx * inr, uy = ry * inr, uz = rz * inr;
         const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
-        RV_PL(sX, 0, n, c) = (Px - sMean[0]) * sInv[0];
-        RV_PL(sX, 1, n, c) = (Py - sMean[1]) * sInv[1];
-        RV_PL(sX, 2, n, c) = (Pz - sMean[2]) * sInv[2];
-        RV_PL(sX, 9, n, c) = (ux - sMean[9]) * sInv[9];
-        RV_PL(sX, 10, n, c) = (uy - sMean[10]) * sInv[10];
-        RV_PL(sX, 11, n, c) = (uz - sMean[11]) * sInv[11];
-        RV_PL(sX, 12, n, c) = (tension - sMean[12]) * sInv[12];
+        if (uses(0)) RV_PL(sX, 0, n, c) = (Px - sMean[0]) * sInv[0];
+        if (uses(1)) RV_PL(sX, 1, n, c) = (Py - sMean[1]) * sInv[1];
+        if (uses(2)) RV_PL(sX, 2, n, c) = (Pz - sMean[2]) * sInv[2];
+        if (uses(9)) RV_PL(sX, 9, n, c) = (ux - sMean[9]) * sInv[9];
+        if (uses(10)) RV_PL(sX, 10, n, c) = (uy - sMean[10]) * sInv[10];
+        if (uses(11)) RV_PL(sX, 11, n, c) = (uz - sMean[11]) * sInv[11];
+        if (uses(12)) RV_PL(sX, 12, n, c) = (tension - sMean[12]) * sInv[12];
         if (VT == ROVMPC_VT_COMPOSE) {
             RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
         } else {
@@ -347,13 +356,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T ap = (Vx * ux + Vy * uy + Vz * uz) / nv;
             const int apslot = a.fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
             if (a.fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
-            RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
-            RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
-            RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
-            RV_PL(sX, 6, n, c) = (Ax - sMean[6]) * sInv[6];
-            RV_PL(sX, 7, n, c) = (Ay - sMean[7]) * sInv[7];
-            RV_PL(sX, 8, n, c) = (Az - sMean[8]) * sInv[8];
-            RV_PL(sX, 13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
+            if (uses(3)) RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
+            if (uses(4)) RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
+            if (uses(5)) RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
+            if (uses(6)) RV_PL(sX, 6, n, c) = (Ax - sMean[6]) * sInv[6];
+            if (uses(7)) RV_PL(sX, 7, n, c) = (Ay - sMean[7]) * sInv[7];
+            if (uses(8)) RV_PL(sX, 8, n, c) = (Az - sMean[8]) * sInv[8];
+            if (uses(13)) RV_PL(sX, 13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
         }
     }
     __syncthreads();
@@ -623,24 +632,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // generic path: full 18-slot feature row per stage, bytecode interpreter
             T Vx = V0x, Vy = V0y, Vz = V0z;
             auto store_vslots = [&](int node, T vx, T vy, T vz, T ax, T ay, T az) {
-                const T ux = RV_PL(sA, 5, node, c), uy = RV_PL(sA, 6, node, c), uz = RV_PL(sA, 7, node, c);
-                const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
-                T ap = (vx * ux + vy * uy + vz * uz) / nv;
-                const int apslot = gen2 ? 16 : 13;
-                if (!gen2) ap = m_clip(ap, T(-1), T(1));
-                RV_PL(sX, 3, node, c) = (vx - sMean[3]) * sInv[3];
-                RV_PL(sX, 4, node, c) = (vy - sMean[4]) * sInv[4];
-                RV_PL(sX, 5, node, c) = (vz - sMean[5]) * sInv[5];
-                RV_PL(sX, 6, node, c) = (ax - sMean[6]) * sInv[6];
-                RV_PL(sX, 7, node, c) = (ay - sMean[7]) * sInv[7];
-                RV_PL(sX, 8, node, c) = (az - sMean[8]) * sInv[8];
-                RV_PL(sX, 13, node, c) = (ap - sMean[apslot]) * sInv[apslot];
+                if (uses(13)) {
+                    const T ux = RV_PL(sA, 5, node, c), uy = RV_PL(sA, 6, node, c), uz = RV_PL(sA, 7, node, c);
+                    const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
+                    T ap = (vx * ux + vy * uy + vz * uz) / nv;
+                    const int apslot = gen2 ? 16 : 13;
+                    if (!gen2) ap = m_clip(ap, T(-1), T(1));
+                    RV_PL(sX, 13, node, c) = (ap - sMean[apslot]) * sInv[apslot];
+                }
+                if (uses(3)) RV_PL(sX, 3, node, c) = (vx - sMean[3]) * sInv[3];
+                if (uses(4)) RV_PL(sX, 4, node, c) = (vy - sMean[4]) * sInv[4];
+                if (uses(5)) RV_PL(sX, 5, node, c) = (vz - sMean[5]) * sInv[5];
+                if (uses(6)) RV_PL(sX, 6, node, c) = (ax - sMean[6]) * sInv[6];
+                if (uses(7)) RV_PL(sX, 7, node, c) = (ay - sMean[7]) * sInv[7];
+                if (uses(8)) RV_PL(sX, 8, node, c) = (az - sMean[8]) * sInv[8];
             };
-            if (VT == ROVMPC_VT_COMPOSE) store_vslots(0, Vx, Vy, Vz, A0x, A0y, A0z);
+            const bool vel_used = (used & 0x21f8u) != 0;     // planes 3..8, 13
+            if (VT == ROVMPC_VT_COMPOSE && vel_used) store_vslots(0, Vx, Vy, Vz, A0x, A0y, A0z);
             T *feat = sF + c;                       // [slot][lane]
             T *stack = sF + 18 * CK + c;
             for (int n = 0; n < nsteps; ++n) {
-                if (VT == ROVMPC_VT_COMPOSE) {
+                if (VT == ROVMPC_VT_COMPOSE && vel_used) {
                     const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
                     const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
                     T st, ct, sg, cg;
@@ -682,6 +694,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         return;
                     }
                     for (int s = 0; s < NEXO; ++s) {
+                        if (!uses(s)) continue;
                         T v;
                         if (cfrac2 == 0) v = RV_PL(sX, s, n, c);
                         else if (cfrac2 == 2) v = RV_PL(sX, s, n + 1, c);

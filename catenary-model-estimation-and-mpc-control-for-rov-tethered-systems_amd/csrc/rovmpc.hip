@@ -34,6 +34,7 @@ struct rovmpc_handle {
     int n_feat = 0;
     double mean[ROVMPC_MAX_FEATURES], scale[ROVMPC_MAX_FEATURES];
     int n_th = 0, n_ga = 0, n_consts = 0;
+    unsigned used_planes = 0xffffffffu;   // exogenous planes read by the loaded expressions
     int32_t *d_code_th = nullptr, *d_code_ga = nullptr;
     void *d_consts = nullptr;        // T
     double *d_consts64 = nullptr;    // double (utility kernels)
@@ -350,7 +351,7 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
                               const double *consts) {
     const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
     std::string s;
-    s += "#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
+    s += "#define ROVMPC_JIT_USED " + std::to_string(h->used_planes) + "u\n#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
     s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
     s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
          "while (ae) { if (ae & 1) r *= b; b *= b; ae >>= 1; } return e < 0 ? T(1) / r : r; }\n";
@@ -479,6 +480,20 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
             same = fabs(gt - rt) <= 1e-12 * (1.0 + fabs(rt)) && fabs(gg - rg) <= 1e-12 * (1.0 + fabs(rg));
         }
     }
+    {
+        // exogenous planes the expressions read (plane 13 = angle_proj: feature 13, or 16 in generation 2)
+        unsigned m = 0;
+        auto scan = [&](const int32_t *code, int n) {
+            for (int pc = 0; pc < n; ++pc)
+                if ((code[pc] & 0xff) == ROVMPC_OP_PUSH_F) {
+                    const int f = code[pc] >> 8;
+                    if (h->cfg.feature_map == ROVMPC_FEATURES_GEN2) { if (f < 12) m |= 1u << f; else if (f == 16) m |= 1u << 13; }
+                    else if (f < 14) m |= 1u << f;
+                }
+        };
+        scan(code_theta, n_code_theta); scan(code_gamma, n_code_gamma);
+        h->used_planes = m;
+    }
     h->builtin = same;
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
     h->jit_fn = nullptr;
@@ -527,6 +542,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
     a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags; a.fmap = c.feature_map;
+    a.used_planes = h->used_planes;
     a.ck_shift = 0;
     while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
