@@ -1,0 +1,54 @@
+/* Plain-C consumer of librovmpc.so: proves the boundary is a C ABI (no Python, no torch).
+ * Build: gcc -O2 -I include tests/c_abi/c_abi_smoke.c -o /tmp/c_abi_smoke -L <pkg>/lib -lrovmpc -lm
+ * It checks solve_catenary against the reference's known answers, runs one MPC step with a
+ * model given as bytecode, and checks the arg-min against the costs returned by the same library. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "rovmpc.h"
+
+#define CHECK(h, call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, rovmpc_last_error(h)); return 1; } } while (0)
+
+int main(void) {
+    rovmpc_config cfg;
+    rovmpc_default_config(&cfg);
+    cfg.N = 10; cfg.K = 128;
+    rovmpc_handle *h = NULL;
+    CHECK(NULL, rovmpc_create(&cfg, &h));
+
+    /* main_fun.solve_catenary known answers (L = 3) */
+    const double l[7] = {1.0, 1.41421356, 2.0, 2.5, 2.9, 0.5, 3.5}, dH[7] = {0, -1, 0.5, -0.3, 0.1, 0, 0};
+    const double want[5] = {5.676892760096155, 3.0791940475045547, 1.5916068034624558, 0.8396630142778874, 0.309507897379277};
+    double C[7], T[7];
+    CHECK(h, rovmpc_solve_catenary(h, l, dH, 3.0, 7, C, T));
+    for (int i = 0; i < 5; ++i)
+        if (fabs(C[i] - want[i]) > 1e-11) { fprintf(stderr, "C[%d] = %.17g, want %.17g\n", i, C[i], want[i]); return 1; }
+    if (!isnan(C[5]) || !isnan(C[6])) { fprintf(stderr, "expected NaN for the two no-root cases\n"); return 1; }
+    if (fabs(T[5] - 1.521 / 3.0 * 0.5 / 2) > 1e-15) { fprintf(stderr, "tension fallback wrong\n"); return 1; }
+
+    /* model: dtheta/dt = -0.05 * x16 - 0.05 * sin(x3), dgamma/dt = x15 - x17 (identity scaler) */
+    double mean[18] = {0}, scale[18];
+    for (int i = 0; i < 18; ++i) scale[i] = 1.0;
+    const double consts[1] = {-0.05};
+    const int32_t th[] = {(0 << 8) | ROVMPC_OP_PUSH_C, (16 << 8) | ROVMPC_OP_PUSH_F, ROVMPC_OP_MUL,
+                          (0 << 8) | ROVMPC_OP_PUSH_C, (3 << 8) | ROVMPC_OP_PUSH_F, ROVMPC_OP_SIN, ROVMPC_OP_MUL, ROVMPC_OP_ADD};
+    const int32_t ga[] = {(15 << 8) | ROVMPC_OP_PUSH_F, (17 << 8) | ROVMPC_OP_PUSH_F, ROVMPC_OP_SUB};
+    CHECK(h, rovmpc_set_model(h, 18, mean, scale, th, 8, ga, 3, consts, 1));
+    printf("model path: %d (0 compiled-in, 1 interpreter, 2 hiprtc)\n", rovmpc_model_path(h));
+
+    rovmpc_state st = {{0, 0, 0}, {0.24, -0.76, 0.30}, {0.5, -0.2, 0.1}, {0, 0, 0}, -0.03, -0.05, -0.03, -0.05};
+    double *U = malloc(sizeof(double) * cfg.K * cfg.N * 3), *J = malloc(sizeof(double) * cfg.K);
+    unsigned s = 12345u;
+    for (int i = 0; i < cfg.K * cfg.N * 3; ++i) { s = s * 1664525u + 1013904223u; U[i] = ((double)(s >> 8) / 16777216.0 - 0.5) * 4.0; }
+    double u[3], traj[2 * 11], best; int64_t idx;
+    CHECK(h, rovmpc_step(h, &st, U, u, traj, &best, &idx));
+    CHECK(h, rovmpc_rollout_costs(h, &st, U, J, NULL));
+    int k = 0;
+    for (int i = 1; i < cfg.K; ++i) if (J[i] < J[k]) k = i;
+    if (k != idx || J[k] != best || u[0] != U[(size_t)k * cfg.N * 3]) { fprintf(stderr, "arg-min mismatch: %d vs %lld\n", k, (long long)idx); return 1; }
+    if (traj[0] != st.theta || traj[1] != st.gamma) { fprintf(stderr, "trajectory does not start at the state\n"); return 1; }
+    printf("c_abi_smoke ok: k*=%lld J*=%.12g u=(%.6f %.6f %.6f)\n", (long long)idx, best, u[0], u[1], u[2]);
+    free(U); free(J);
+    rovmpc_destroy(h);
+    return 0;
+}

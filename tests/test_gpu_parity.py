@@ -596,3 +596,16 @@ def test_error_behaviour(rv):
         rv.DynamicsModel(np.zeros(18), np.ones(18), "x3 + foo(x1)", "x15")
     with pytest.raises(rv.ExpressionError):
         rv.DynamicsModel(np.zeros(18), np.ones(18), "x3 + x99", "x15")
+
+
+def test_plain_c_consumer_of_the_abi(rv, tmp_path):
+    """A C program (gcc, no Python, no torch) links librovmpc.so and drives the hot path."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(rv.LIB_PATH)
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"),
+                    "-o", exe, "-L", libdir, "-lrovmpc", "-lm", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "c_abi_smoke ok" in r.stdout
