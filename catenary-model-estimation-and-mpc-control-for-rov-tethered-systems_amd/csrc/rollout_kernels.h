@@ -374,8 +374,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // phase 4a, item (n, c): node n+1 of candidate c.  Nothing here depends on (theta, gamma):
     // catenary parameter + tension of the straight geometry (main_fun.py:292-293, 303-305),
     // tautness and control terms of the cost.
-    auto geometry_a = [&](int first, int stride, int begin) {
-        for (int i = begin + first; i < ((a.debug & 2) ? 0 : N * CK); i += stride) {
+    // work list of one thread: optionally one own item first, then items begin + first + k stride
+    auto geometry_a = [&](int own_item, int first, int stride, int begin) {
+        const int total = (a.debug & 2) ? 0 : N * CK;
+        bool pending_own = own_item >= 0;
+        for (int i = pending_own ? own_item : begin + first; i < total;) {
             const int n = i >> cks, c = i & ckm;
             const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                     rz = RV_PL(sP, 2, n + 1, c) - P0z;
@@ -388,6 +391,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T e0 = u[0] - kk.Uref[0], e1 = u[1] - kk.Uref[1], e2 = u[2] - kk.Uref[2];
             const T taut = m_max(T(0), d - kk.rhoL);
             sC[n * CK + c] = kk.w_u * (e0 * e0 + e1 * e1 + e2 * e2) + kk.w_T * Tn + kk.w_taut * (taut * taut);
+            if (pending_own) { pending_own = false; i = begin + first; } else i += stride;
         }
     };
 
@@ -581,37 +585,35 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
 
-        if (NT >= nint + 64) {
-            // theta waves | one gamma wave | the rest: phase 4a
-            if (tid < nint) {
-                __builtin_amdgcn_s_setprio(3);       // the workgroup's critical path
-                theta_path();
-                __builtin_amdgcn_s_setprio(0);
-            } else if (tid < nint + 64) {
-                __builtin_amdgcn_s_setprio(2);
-                gamma_path();
-                __builtin_amdgcn_s_setprio(0);
-                geometry_a(tid - nint, NT - nint, early);
-            } else {
-                // Early batch: N*CK items on a workgroup of N*CK threads are one wave more than the
-                // CU has SIMDs (320 items = 5 waves on 4 SIMDs: one SIMD would issue two waves' worth
-                // of phase 4b after the join).  The first `early` items -- the nodes the theta wave
-                // finishes first -- are therefore taken through 4a AND 4b by an otherwise idle wave
-                // while the integration is still running; the join then leaves a multiple of 256.
-                const int j = tid - nint - 64;
-                if (j < early && !(a.debug & 2)) geometry_a(j, 1 << 30, 0);
-                geometry_a(tid - nint, NT - nint, early);
-                if (j < early && !(a.debug & 2)) {
-                    const int n = j >> cks;
-                    while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
-                    geometry_b_item(n, j & ckm);
-                }
-            }
-        } else {
-            if (tid < 64) gamma_path();              // tiny workgroups: gamma path first, same wave
-            __syncthreads();
-            if (tid < nint) theta_path();
-            geometry_a(tid, NT, 0);
+        // Dispatch (every routine has ONE call site: the kernel is run once through per launch, so
+        // its size is instruction-cache misses).  Wide workgroups: theta waves | one gamma wave |
+        // the rest.  Narrow ones (a single wave): gamma path first, then the theta path.
+        const bool wide = NT >= nint + 64;
+        const bool is_gamma = wide ? (tid >= nint && tid < nint + 64) : (tid < 64);
+        if (is_gamma) {
+            __builtin_amdgcn_s_setprio(2);
+            gamma_path();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (!wide) __syncthreads();
+        if (tid < nint) {
+            __builtin_amdgcn_s_setprio(3);           // the workgroup's critical path
+            theta_path();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // Phase 4a pool = every thread that does not integrate theta (all threads when narrow).
+        // Early batch: N*CK items on a workgroup of N*CK threads are one wave more than the CU has
+        // SIMDs (320 items = 5 waves on 4 SIMDs: one SIMD would issue two waves' worth of phase 4b
+        // after the join).  The first `early` items -- the nodes the theta wave finishes first --
+        // are therefore taken through 4a AND 4b by an otherwise idle wave while the integration is
+        // still running; the join then leaves a multiple of 256.
+        const int j = wide ? tid - nint - 64 : -1;
+        const bool own = j >= 0 && j < early && !(a.debug & 2);
+        if (!wide || tid >= nint) geometry_a(own ? j : -1, wide ? tid - nint : tid, wide ? NT - nint : NT, early);
+        if (own) {
+            const int n = j >> cks;
+            while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
+            geometry_b_item(n, j & ckm);
         }
     } else {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
@@ -731,16 +733,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
             }
         };
-        if (NT > nint) {
-            if (tid < nint) {
-                integrate();
-            } else {
-                geometry_a(tid - nint, NT - nint, 0);
-            }
-        } else {
-            integrate();
-            geometry_a(tid, NT, 0);
-        }
+        const bool wide = NT > nint;
+        if (tid < nint) integrate();
+        if (!wide || tid >= nint) geometry_a(-1, wide ? tid - nint : tid, wide ? NT - nint : NT, 0);
     }
     __syncthreads();
 
