@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--K", type=int, default=4096, help="candidates per GPU")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--ck", type=int, default=0, help="candidates per workgroup (0 = auto)")
+    ap.add_argument("--nt", type=int, default=0, help="threads per workgroup (0 = auto)")
     ap.add_argument("--pools", type=int, default=8)
     ap.add_argument("--torch-collective", action="store_true", help="use torch.distributed for the all-reduce instead of the library's own RCCL call")
     ap.add_argument("--force-collective", action="store_true",
@@ -106,7 +107,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
-                           candidates_per_block=args.ck, force_interpreter=args.interp, debug_flags=args.debug_flags)
+                           candidates_per_block=args.ck, threads_per_block=args.nt, force_interpreter=args.interp, debug_flags=args.debug_flags)
     S = max(1, args.streams) if (world == 1 and not args.force_collective) else 1
     model = rovmpc.default_model()
     if args.model == "jit-default":

@@ -33,7 +33,7 @@ class Config(C.Structure):
         ("K", C.c_int32), ("n_shape_pts", C.c_int32), ("vt_mode", C.c_int32), ("prev_mode", C.c_int32),
         ("integrator", C.c_int32), ("frame", C.c_int32), ("force_interpreter", C.c_int32),
         ("candidates_per_block", C.c_int32), ("debug_flags", C.c_int32), ("jit_off", C.c_int32),
-        ("feature_map", C.c_int32), ("reserved1", C.c_int32),
+        ("feature_map", C.c_int32), ("threads_per_block", C.c_int32),
         ("dt", C.c_double), ("v_scale", C.c_double), ("L", C.c_double), ("cable_wet_weight", C.c_double),
         ("c_lo", C.c_double), ("c_hi", C.c_double),
         ("w_theta", C.c_double), ("w_gamma", C.c_double), ("w_u", C.c_double), ("w_T", C.c_double),

@@ -190,8 +190,12 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
 // product library contains none of this code.
 #ifdef ROVMPC_STAMPS
 #define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// slot i <- HW_ID (hwreg 4: wave, simd, pipe, cu, sh, se) | XCC_ID (hwreg 20) << 32: which CU ran the workgroup
+#define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = \
+    (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
 #else
 #define RV_STAMP(i) do { } while (0)
+#define RV_STAMP_HW(i) do { } while (0)
 #endif
 
 // LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
@@ -289,7 +293,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     __syncthreads();
 
     RV_STAMP(1);
-    RV_STAMP(2);
+    RV_STAMP_HW(2);
     // ---- phase 2: exogenous feature rows of every node ------------------------------------
     // V_n (feature-frame velocity at node n) when it does not depend on (theta, gamma)
     auto vel = [&](int c, int node, T &vx, T &vy, T &vz) {

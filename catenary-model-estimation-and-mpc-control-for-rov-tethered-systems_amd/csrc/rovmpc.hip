@@ -128,18 +128,83 @@ static int pick_ck(const rovmpc_config *c, int model) {
     return ck;
 }
 
+// Registers per lane of the compiled-in kernel for this handle's (dtype, vt_mode), from the code object.
+static int builtin_kernel_regs(const rovmpc_handle *h) {
+    const void *f = nullptr;
+    const int vt = h->cfg.vt_mode;
+    if (h->cfg.dtype == ROVMPC_F64)
+        f = vt == 0 ? (const void *)rollout_kernel<double, MODEL_BUILTIN, 0> : vt == 1 ? (const void *)rollout_kernel<double, MODEL_BUILTIN, 1>
+                                                                                     : (const void *)rollout_kernel<double, MODEL_BUILTIN, 2>;
+    else
+        f = vt == 0 ? (const void *)rollout_kernel<float, MODEL_BUILTIN, 0> : vt == 1 ? (const void *)rollout_kernel<float, MODEL_BUILTIN, 1>
+                                                                                    : (const void *)rollout_kernel<float, MODEL_BUILTIN, 2>;
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, f) != hipSuccess || fa.numRegs <= 0) return 128;
+    return fa.numRegs;
+}
+
+// Throughput geometry of the compiled-in model when the candidate set is more than one 16-candidate
+// workgroup per CU.  A workgroup alone on a CU spends most of its life in the sequential theta chain
+// (one wave issuing every ~6 cycles), so what matters is how many waves are RESIDENT per CU:
+//   wave slots per SIMD  S = 512 / registers per lane (f64: 3, f32: 6);
+//   workgroups per CU by slots: w = NT/64 waves each; w <= 4 -> 4S / w, w > 4 -> S / ceil(w / 4)
+//     (measured with the HW_ID stamp of the diagnostic build: a 5-wave workgroup of the f64 kernel is
+//      alone on its CU, 4-wave ones run three at a time, 3-wave ones four);
+//   workgroups per CU by LDS: 160 KiB / bytes per workgroup.
+// Choose (CK, NT) maximising resident waves, then resident candidates, then CK (the candidate-
+// invariant gamma wave is paid once per workgroup).  CK stays >= 16: fewer leaves theta-wave lanes
+// idle.  tools/geometry_sweep.py measures the whole grid; this rule picks its minimum at
+// (N 20, f64), (N 20, f32), (N 50, f32) and (N 50, f64) for K = 8192 .. 32768.
+static bool throughput_geometry(const rovmpc_handle *h, int n_cu, int *ck_out, int *nt_out) {
+    const rovmpc_config *c = &h->cfg;
+    if ((c->K + 15) / 16 <= n_cu) return false;
+    int alloc = (builtin_kernel_regs(h) + 7) / 8 * 8;
+    int S = 512 / alloc; if (S > 8) S = 8; if (S < 1) S = 1;
+    long best_w = -1, best_c = -1; int best_ck = 0, best_nt = 0;
+    for (int ck = 16; ck <= 64; ck *= 2) {
+        const size_t lds = lds_need(c, ck, MODEL_BUILTIN);
+        if (lds > 160 * 1024) break;
+        const int by_lds = (int)((160 * 1024) / lds);
+        for (int nt = 256; nt <= 512; nt += 128) {
+            const int w = nt / 64;
+            if (w < ck / 16 + 2) continue;                 // theta waves + gamma wave + one geometry wave
+            const int by_slots = w <= 4 ? 4 * S / w : S / ((w + 3) / 4);
+            const int R = by_slots < by_lds ? by_slots : by_lds;
+            if (R < 1) continue;
+            const long W = (long)R * w, Cn = (long)R * ck;
+            if (W > best_w || (W == best_w && (Cn > best_c || (Cn == best_c && ck > best_ck)))) {
+                best_w = W; best_c = Cn; best_ck = ck; best_nt = nt;
+            }
+        }
+    }
+    if (best_ck == 0) return false;
+    *ck_out = best_ck; *nt_out = best_nt;
+    return true;
+}
+
 // Launch geometry for the model variant in use.  The per-block buffers are allocated for the
 // worst case (one candidate per workgroup) so re-deciding it at set_model needs no allocation.
-static const char *configure_geometry(rovmpc_handle *h, int model) {
+// strict = false (rovmpc_create, model not known yet): an explicit candidates_per_block that the
+// interpreter's LDS layout cannot hold is not an error until a model that needs it is set.
+static const char *configure_geometry(rovmpc_handle *h, int model, bool strict = true) {
     const rovmpc_config *cfg = &h->cfg;
     h->CK = pick_ck(cfg, model);
-    h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
     // the per-node geometry phase is a single round
     int items = cfg->N * h->CK;
     h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
+    if (strict && model == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
+        hipDeviceProp_t prop{};
+        int ck = 0, nt = 0;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess &&
+            throughput_geometry(h, prop.multiProcessorCount, &ck, &nt)) {
+            h->CK = ck; h->NT = nt;
+        }
+    }
+    h->nblocks = (cfg->K + h->CK - 1) / h->CK;
+    if (cfg->threads_per_block > 0) h->NT = cfg->threads_per_block;
     if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
-    if (lds_need(cfg, h->CK, model) > 160 * 1024)
+    if (strict && lds_need(cfg, h->CK, model) > 160 * 1024)
         return "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
     return nullptr;
 }
@@ -166,6 +231,8 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64 ||
         (cfg->candidates_per_block & (cfg->candidates_per_block - 1)) != 0)
         FAIL(nullh, ROVMPC_ERR_INVALID, "candidates_per_block must be 0 (auto) or a power of two <= 64");
+    if (cfg->threads_per_block < 0 || cfg->threads_per_block > 512 || cfg->threads_per_block % 64 != 0)
+        FAIL(nullh, ROVMPC_ERR_INVALID, "threads_per_block must be 0 (auto) or a multiple of 64 up to 512");
     if ((long long)cfg->N * 3 * 64 >= 65536) FAIL(nullh, ROVMPC_ERR_INVALID, "N must be below 341 (LDS-resident horizon)");
 
     int ndev = 0;
@@ -178,7 +245,7 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *h = new rovmpc_handle();
     h->cfg = *cfg;
     h->esz = cfg->dtype == ROVMPC_F64 ? 8 : 4;
-    if (const char *why = configure_geometry(h, MODEL_INTERP)) {
+    if (const char *why = configure_geometry(h, MODEL_INTERP, false)) {
         g_create_error = why;
         delete h;
         return ROVMPC_ERR_INVALID;
@@ -558,6 +625,17 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, hi
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+#ifdef ROVMPC_STAMPS
+    static bool told = false;
+    if (!told && getenv("ROVMPC_DIAG_OCCUPANCY")) {
+        told = true;
+        int nb = -1; hipFuncAttributes fa{};
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, h->NT, lds);
+        hipFuncGetAttributes(&fa, (const void *)kern);
+        fprintf(stderr, "[rovmpc diag] NT %d lds %zu: resident workgroups/CU %d; regs %d static lds %zu scratch %zu maxThreads %d\n",
+                h->NT, lds, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(h->NT), lds, s, a);
     return hipGetLastError();
 }

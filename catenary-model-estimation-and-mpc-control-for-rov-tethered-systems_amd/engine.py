@@ -29,6 +29,7 @@ class MPCConfig:
     frame: str = "ENU"
     force_interpreter: bool = False
     candidates_per_block: int = 0
+    threads_per_block: int = 0
     debug_flags: int = 0
     jit: bool = True             # specialise non-default models with hiprtc at set_model
     feature_map: int = _lib.FEATURES_GEN1   # FEATURES_GEN2: 17 unscaled slots of simulate_rk4_theta_gamma.py:12-42
@@ -64,6 +65,7 @@ class MPCConfig:
         c.frame = _lib.ENU if self.frame == "ENU" else _lib.NED
         c.force_interpreter = int(self.force_interpreter)
         c.candidates_per_block = self.candidates_per_block
+        c.threads_per_block = self.threads_per_block
         c.debug_flags = self.debug_flags
         c.jit_off = 0 if self.jit else 1
         c.feature_map = self.feature_map

@@ -109,7 +109,7 @@ typedef struct rovmpc_config {
     int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
     int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
     int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | ROVMPC_FEATURES_GEN2              */
-    int32_t reserved1;
+    int32_t threads_per_block;  /* 0 = auto; else a multiple of 64 in 64..512                */
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
     double L;                   /* cable length [m] (test_cluster.py:22)                    */

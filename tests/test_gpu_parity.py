@@ -393,6 +393,40 @@ def test_workgroup_shapes_of_the_compiled_in_path(rv, orc, N, K, ck, vt, prev, i
     assert res.index == int(np.argmin(Jo))
 
 
+@pytest.mark.parametrize("N,K,ck,nt,dtype", [(20, 600, 16, 256, "f64"), (20, 600, 32, 512, "f64"), (20, 300, 16, 192, "f64"),
+                                             (20, 300, 8, 128, "f64"), (20, 200, 16, 64, "f64"), (50, 200, 16, 512, "f64"),
+                                             (20, 600, 32, 512, "f32"), (20, 600, 64, 512, "f32"), (20, 600, 32, 192, "f64")])
+def test_throughput_geometries(rv, orc, N, K, ck, nt, dtype):
+    """threads_per_block: the (candidates, threads) per workgroup pairs the library's throughput rule can
+    choose for large candidate sets, plus a narrow one-wave workgroup; results must not depend on it."""
+    cfg = rv.MPCConfig(N=N, K=K, candidates_per_block=ck, threads_per_block=nt, dtype=dtype)
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg)
+    if dtype == "f64":
+        np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+        np.testing.assert_allclose(J, Jo, rtol=RTOL)
+        assert res.index == int(np.argmin(Jo))
+    else:
+        assert np.median(np.abs(J - Jo) / np.abs(Jo)) < 1e-5
+        assert np.abs(traj - trajo).max() / np.abs(trajo).max() < 1e-4
+
+
+def test_auto_geometry_large_candidate_set(rv, orc):
+    """K = 16384, N = 20, fp64: more than one 16-candidate workgroup per CU, the library switches to its
+    throughput geometry; k*, u and the trajectory still equal the oracle's."""
+    cfg = rv.MPCConfig(N=20, K=16384)
+    (J, traj, res), (Jo, trajo, aux), (state, U) = run_both(rv, orc, cfg)
+    k = int(np.argmin(Jo))
+    assert res.index == k and np.array_equal(res.u, U[k, 0])
+    np.testing.assert_allclose(res.traj, trajo[k], rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+
+
+def test_threads_per_block_is_validated(rv):
+    for bad in (100, 576, -64):
+        with pytest.raises(rv.RovmpcError):
+            rv.Engine(rv.MPCConfig(N=4, K=8, threads_per_block=bad))
+
+
 def test_geometry_edge_cases_in_rollout(rv, orc):
     """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
     a vertical cable (degenerate xy projection)."""

@@ -25,9 +25,28 @@ nb = C.c_int32()
 assert lib.rovmpc_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
 st = buf[:nb.value].astype(np.int64)
 t0 = st[:, 0].min()
-names = ["start", "U in LDS", "prefix done", "features done", "integration done", "geometry done", "outputs stored", "ticket drawn"]
+names = ["start", "U in LDS", None, "features done", "integration done", "geometry done", "outputs stored", "ticket drawn"]
 print(f"{nb.value} workgroups; times in us from the first workgroup's start (100 MHz clock)")
 for i, n in enumerate(names):
+    if n is None:
+        continue
     col = st[:, i]
     col = col[col > 0]
     print(f"  {n:18s} median {np.median(col - t0) / 100:7.2f}   min {(col.min() - t0) / 100:7.2f}   max {(col.max() - t0) / 100:7.2f}")
+
+# residency: which CU ran each workgroup (HW_ID / XCC_ID stamp), how many were alive together
+hw = buf[:nb.value, 2]
+cu = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64) * 4096 + ((hw >> np.uint64(8)) & np.uint64(0xFF)).astype(np.int64)
+start, end = st[:, 0], st[:, 7]
+dur = (end - start) / 100
+print(f"workgroup lifetime us: median {np.median(dur):.2f}  p10 {np.percentile(dur, 10):.2f}  p90 {np.percentile(dur, 90):.2f}")
+ev = np.concatenate([np.stack([start, np.ones_like(start)], 1), np.stack([end, -np.ones_like(end)], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+print(f"distinct CUs {len(np.unique(cu))}; peak workgroups alive on the chip {np.cumsum(ev[:, 1]).max()}")
+peaks = []
+for c in np.unique(cu):
+    m = cu == c
+    e = np.concatenate([np.stack([start[m], np.ones(m.sum(), np.int64)], 1), np.stack([end[m], -np.ones(m.sum(), np.int64)], 1)])
+    e = e[np.argsort(e[:, 0], kind="stable")]
+    peaks.append(np.cumsum(e[:, 1]).max())
+print(f"peak workgroups alive per CU: median {np.median(peaks):.0f}  max {max(peaks)}; workgroups per CU median {np.median(np.bincount(np.unique(cu, return_inverse=True)[1])):.0f}")
