@@ -187,6 +187,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last = rec.cpu().numpy()
+    ranks_agree = None
+    if dist is not None and world > 1:      # every rank must hold the same global record after the all-reduce
+        allrec = [None] * world
+        dist.all_gather_object(allrec, last.tolist())
+        ranks_agree = all(r == allrec[0] for r in allrec)
     kavg_ms = region_ms / args.steps
     # second, untimed pass: per-launch event pairs around the rollout kernel alone (each pair
     # costs ~3 us of its own, so this pass is not the one `value` comes from)
@@ -222,6 +227,7 @@ def main():
                        "collective": collective,
                        "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
             "best": {"cost": float(last[0]), "index": int(last[1])},
+            "ranks_agree": ranks_agree,
         }
         if kavg_ms:
             achieved = alg_bytes / (kavg_ms * 1e-3) / 1e9

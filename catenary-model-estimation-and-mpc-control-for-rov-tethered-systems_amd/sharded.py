@@ -150,11 +150,34 @@ class NativeShardedMPC:
         K_local = engine.cfg.K
         self.K_total = K_total if K_total is not None else K_local * self.world
         self.k_offset = shard_bounds(self.K_total, self.rank, self.world)[0]
-        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        dev = torch.device("cuda", engine.cfg.device)
+        # Every rank must take the same path: a rank-0 failure is broadcast (None) instead of
+        # leaving the others in the broadcast, and the outcome of ncclCommInitRank is agreed by
+        # one all-reduce(MIN) before anybody uses the communicator.
+        box, err = [None], None
+        if self.rank == 0:
+            try:
+                box[0] = engine.comm_unique_id()
+            except Exception as exc:                      # noqa: BLE001
+                err = exc
         if self.world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
-        engine.comm_init(box[0], self.rank, self.world)
-        dev = torch.device("cuda", engine.cfg.device)
+        if box[0] is None:
+            raise RuntimeError(f"RCCL id not available on rank 0: {err}")
+        try:
+            engine.comm_init(box[0], self.rank, self.world)
+        except Exception as exc:                          # noqa: BLE001
+            err = exc
+        if self.world > 1:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32,
+                              device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if err is None:
+                    engine.comm_destroy()
+                raise RuntimeError(f"ncclCommInitRank failed on at least one rank (this rank: {err})")
+        elif err is not None:
+            raise err
         self.R = engine.result_len
         self.results = [torch.empty(self.R, dtype=torch.float64, device=dev) for _ in range(self.SLOTS)]
         self._flip = 0

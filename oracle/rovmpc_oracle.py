@@ -57,9 +57,10 @@ class SymbolicModel:
     namespace (independent of the product's bytecode compiler).
     """
 
-    def __init__(self, sympy_format: str, n_features: int = 18):
+    def __init__(self, sympy_format: str, n_features: int = 18, variable_names: Optional[Sequence[str]] = None):
         self.expr = sympy_format.strip()
         self.n_features = n_features
+        self.variable_names = list(variable_names) if variable_names else None   # dd_cluster.py:160-168
         self._code = compile(self.expr, "<sympy_format>", "eval")
 
     def __call__(self, xs: Sequence) -> np.ndarray:
@@ -67,6 +68,9 @@ class SymbolicModel:
         ns = dict(_EXPR_NS)
         for i in range(len(xs)):
             ns[f"x{i}"] = xs[i]
+        if self.variable_names:
+            for nm, x in zip(self.variable_names, xs):
+                ns[nm] = x
         with np.errstate(all="ignore"):
             out = eval(self._code, {"__builtins__": {}}, ns)  # noqa: S307 (trusted fixture text)
         return out
@@ -439,7 +443,7 @@ class MPCConfig:
     theta_ref: float = 0.0
     gamma_ref: float = 0.0
     U_ref: Tuple[float, float, float] = (0.0, 0.0, 0.0)
-    feature_map: int = 0             # 0: 18 scaled slots (simply.py:15-41); 1: 17 unscaled slots (simulate_rk4_theta_gamma.py:12-42)
+    feature_map: int = 0             # 0: 18 scaled slots (simply.py:15-41); 1: 17 unscaled slots (simulate_rk4_theta_gamma.py:12-42); 2: features_dd, second order (rollout_vec_dd)
 
 
 @dataclass
@@ -754,6 +758,181 @@ def rollout_vec(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=N
             Tn[:, n] = T; Zn[:, n] = z_low; Cn[:, n] = C
     J = np.where(np.isnan(J), np.inf, J)
     return J, traj, {"T": Tn, "z_low": Zn, "C": Cn}
+
+
+# --------------------------------------------------------------------------------------
+# N2 -- second-order models: features_dd (main_fun.py:811-871) and the closed-loop rollout on
+#       the state (theta, gamma, dtheta, dgamma)
+# --------------------------------------------------------------------------------------
+
+DD_NAMES = ("theta", "gama", "dtheta", "dgamma", "v_sway", "v_surge", "a_sway", "a_surge",
+            "V_x", "V_y", "V_z", "a_x", "a_y", "a_z")          # dd_cluster.py:160-168
+
+
+def features_dd(P0_mm, P1_mm, V_mm, time, theta_raw, gamma_raw):
+    """main_fun.py:811-871 on arrays: returns (features(T,14), targets(T,2))."""
+    from scipy.signal import savgol_filter
+    P0 = np.asarray(P0_mm, float) / 1000; P1 = np.asarray(P1_mm, float) / 1000; V1 = np.asarray(V_mm, float) / 1000   # :813-815
+    t = np.asarray(time, float)
+    a = np.stack([np.gradient(V1[:, j], t) for j in range(3)], axis=1)                       # :825-827
+    th = savgol_filter(np.asarray(theta_raw, float), window_length=11, polyorder=3)          # :830-831
+    ga = savgol_filter(np.asarray(gamma_raw, float), window_length=11, polyorder=3)
+    dth = np.gradient(th, t); dga = np.gradient(ga, t)                                       # :833-834
+    ddth = np.gradient(dth, t); ddga = np.gradient(dga, t)                                   # :835-836
+    rel = P1 - P0
+    unit = rel / (np.linalg.norm(rel, axis=1, keepdims=True) + 1e-8)                         # :841
+    v_surge = np.sum(V1 * unit, axis=1)                                                      # :842
+    v_sway = np.linalg.norm(np.cross(V1, unit), axis=1)                                      # :843
+    a_surge = np.gradient(v_surge, t); a_sway = np.gradient(v_sway, t)                       # :846-847
+    feats = np.stack([th, ga, dth, dga, v_sway, v_surge, a_sway, a_surge,
+                      V1[:, 0], V1[:, 1], V1[:, 2], a[:, 0], a[:, 1], a[:, 2]], axis=1)       # :849-864
+    return feats, np.stack([ddth, ddga], axis=1)
+
+
+def _dd_surge_sway(P0, P, Vm):
+    rel = P - P0
+    unit = rel / (np.linalg.norm(rel, axis=-1, keepdims=True) + 1e-8)
+    return np.linalg.norm(np.cross(Vm, unit), axis=-1), np.sum(Vm * unit, axis=-1)            # sway, surge
+
+
+def rollout_vec_dd(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=None):
+    """Closed-loop rollout of a SECOND-order model pair (ddtheta, ddgamma) = f(scaled features_dd row),
+    build-defined like the first-order one:  y = (theta, gamma, dtheta, dgamma),
+    y' = (dtheta, dgamma, f_theta(x), f_gamma(x)); classic RK4 (integrator 0) or the reference's explicit
+    double Euler (test_cluster.py:110-129, integrator 1).  Row x: slots 0-3 the stage state, slots 4-13
+    exogenous (surge/sway speeds and their first differences, V and A in m/s), interpolated between
+    nodes n and n+1 at the midpoint stages (simulate_rk4_theta_gamma.py:62).  a_sway/a_surge at node 0
+    take np.gradient's edge rule (= the first difference of nodes 0,1, main_fun.py:846-847).
+    ``state.theta_prev / gamma_prev`` carry dtheta_0 / dgamma_0 in this map."""
+    U = np.asarray(U, float)
+    K, N, _ = U.shape
+    mean, scale = np.asarray(model.mean, float), np.asarray(model.scale, float)
+    h, vs = cfg.dt, cfg.v_scale
+    P0 = np.asarray(state.P0, float)
+    P = np.tile(np.asarray(state.P1, float), (K, 1))
+    V = np.tile(np.asarray(state.V1, float), (K, 1))
+    A = np.tile(np.asarray(state.A1, float), (K, 1))
+    th = np.full(K, float(state.theta)); ga = np.full(K, float(state.gamma))
+    dth = np.full(K, float(state.theta_prev)); dga = np.full(K, float(state.gamma_prev))
+    Uref = np.asarray(cfg.U_ref, float)
+    traj = np.zeros((K, N + 1, 2)); traj[:, 0, 0] = th; traj[:, 0, 1] = ga
+    J = np.zeros(K)
+    Tn = np.zeros((K, N)); Zn = np.zeros((K, N)); Cn = np.zeros((K, N))
+
+    def f(cols):
+        a = np.broadcast_to(np.asarray(model.f_theta(cols), float), (K,))
+        b = np.broadcast_to(np.asarray(model.f_gamma(cols), float), (K,))
+        return a, b
+
+    def exo_row(sway, surge, a_sway, a_surge, Vm, Am):
+        x = np.stack([sway, surge, a_sway, a_surge, Vm[:, 0], Vm[:, 1], Vm[:, 2], Am[:, 0], Am[:, 1], Am[:, 2]], axis=1)
+        return (x - mean[4:14]) / scale[4:14]
+
+    with np.errstate(all="ignore"):
+        sway, surge = _dd_surge_sway(P0, P, vs * V)
+        xs_n = None
+        for n in range(N):
+            Uw = U[:, n, :]
+            if cfg.vt_mode == 0:
+                Vn = Uw.copy()
+            elif cfg.vt_mode == 1:
+                tha, gaa = _axes_vec(P - P0)
+                Vn = _rod_vec(_rod_vec(Uw, gaa, -ga), tha, th)
+            else:
+                Vn = Uw @ np.asarray(Rtab[n], float).reshape(3, 3).T
+            Pn = P + (vs * h) * Uw
+            An = (Vn - V) / h
+            sway_n, surge_n = _dd_surge_sway(P0, Pn, vs * Vn)
+            a_sway_n = (sway_n - sway) / h; a_surge_n = (surge_n - surge) / h
+            if n == 0:
+                xs_n = exo_row(sway, surge, a_sway_n, a_surge_n, vs * V, vs * A)              # edge rule at node 0
+            xs_n1 = exo_row(sway_n, surge_n, a_sway_n, a_surge_n, vs * Vn, vs * An)
+
+            def stage(y, c):
+                exo = xs_n if c == 0.0 else xs_n1 if c == 1.0 else (xs_n + xs_n1) / 2
+                cols = [(y[i] - mean[i]) / scale[i] for i in range(4)] + [exo[:, i] for i in range(10)]
+                ft, fg = f(cols)
+                return (y[2], y[3], ft, fg)
+
+            y = (th, ga, dth, dga)
+            k1 = stage(y, 0.0)
+            if cfg.integrator == 1:
+                yn = tuple(y[i] + k1[i] * h for i in range(4))                                # test_cluster.py:113-129
+            else:
+                k2 = stage(tuple(y[i] + 0.5 * h * k1[i] for i in range(4)), 0.5)
+                k3 = stage(tuple(y[i] + 0.5 * h * k2[i] for i in range(4)), 0.5)
+                k4 = stage(tuple(y[i] + h * k3[i] for i in range(4)), 1.0)
+                yn = tuple(y[i] + (h / 6) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) for i in range(4))
+            th, ga, dth, dga = yn
+            P, V, A = Pn, Vn, An
+            sway, surge = sway_n, surge_n
+            xs_n = xs_n1
+            traj[:, n + 1, 0] = th; traj[:, n + 1, 1] = ga
+
+            rel = P - P0
+            l = np.sqrt(rel[:, 0] ** 2 + rel[:, 1] ** 2); dH = cfg.up * rel[:, 2]
+            d = np.linalg.norm(rel, axis=1)
+            C = solve_catenary_vec(l, dH, cfg.L, cfg.c_lo, cfg.c_hi)
+            T = cable_tension(l, C, cfg.L, cfg.cable_wet_weight)
+            z_low = augmented_lowest_z_vec(P0, P, th, ga, cfg.L, cfg.n_shape_pts, cfg.up, cfg.c_lo, cfg.c_hi)
+            c_n = (cfg.w_theta * (th - cfg.theta_ref) ** 2
+                   + cfg.w_gamma * (ga - cfg.gamma_ref) ** 2
+                   + cfg.w_u * np.sum((Uw - Uref) ** 2, axis=1)
+                   + cfg.w_T * T
+                   + cfg.w_taut * np.maximum(0.0, d - cfg.rho_taut * cfg.L) ** 2
+                   + cfg.w_floor * np.maximum(0.0, cfg.up * (cfg.z_floor - z_low)) ** 2)
+            J = J + c_n
+            Tn[:, n] = T; Zn[:, n] = z_low; Cn[:, n] = C
+    J = np.where(np.isnan(J), np.inf, J)
+    return J, traj, {"T": Tn, "z_low": Zn, "C": Cn, "dtheta": dth, "dgamma": dga}
+
+
+def rollout_scalar_dd(cfg: MPCConfig, model: DynamicsModel, state: MPCState, U, Rtab=None):
+    """Reference-style scalar flavour of ``rollout_vec_dd``: Python loops, one-row ``predict`` per stage.
+    Trajectories only (the node cost is the first-order rollout's, checked there)."""
+    U = np.asarray(U, float)
+    K, N, _ = U.shape
+    mean, scale = np.asarray(model.mean, float), np.asarray(model.scale, float)
+    h, vs = cfg.dt, cfg.v_scale
+    P0 = np.asarray(state.P0, float)
+    traj = np.zeros((K, N + 1, 2))
+    for k in range(K):
+        P = np.asarray(state.P1, float).copy(); V = np.asarray(state.V1, float).copy(); A = np.asarray(state.A1, float).copy()
+        y = np.array([state.theta, state.gamma, state.theta_prev, state.gamma_prev], float)
+        traj[k, 0] = y[:2]
+        sway, surge = _dd_surge_sway(P0, P, vs * V)
+        xs_n = None
+        for n in range(N):
+            Uw = U[k, n]
+            if cfg.vt_mode == 0:
+                Vn = Uw.copy()
+            elif cfg.vt_mode == 1:
+                Vn = velocity_transform_compose(Uw, P - P0, y[0], y[1])
+            else:
+                Vn = np.asarray(Rtab[n], float).reshape(3, 3) @ Uw
+            Pn = P + (vs * h) * Uw
+            An = (Vn - V) / h
+            sway_n, surge_n = _dd_surge_sway(P0, Pn, vs * Vn)
+            a_sw = (sway_n - sway) / h; a_su = (surge_n - surge) / h
+            if n == 0:
+                xs_n = (np.concatenate([[sway, surge, a_sw, a_su], vs * V, vs * A]) - mean[4:14]) / scale[4:14]
+            xs_n1 = (np.concatenate([[sway_n, surge_n, a_sw, a_su], vs * Vn, vs * An]) - mean[4:14]) / scale[4:14]
+
+            def stage(yy, c):
+                exo = xs_n if c == 0.0 else xs_n1 if c == 1.0 else (xs_n + xs_n1) / 2
+                row = np.concatenate([(yy - mean[:4]) / scale[:4], exo]).reshape(1, -1)
+                return np.array([yy[2], yy[3], model.f_theta.predict(row)[0], model.f_gamma.predict(row)[0]])
+
+            with np.errstate(all="ignore"):
+                k1 = stage(y, 0.0)
+                if cfg.integrator == 1:
+                    y = y + h * k1
+                else:
+                    k2 = stage(y + 0.5 * h * k1, 0.5); k3 = stage(y + 0.5 * h * k2, 0.5); k4 = stage(y + h * k3, 1.0)
+                    y = y + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+            P, V, A, sway, surge, xs_n = Pn, Vn, An, sway_n, surge_n, xs_n1
+            traj[k, n + 1] = y[:2]
+    return traj
 
 
 def mpc_step(cfg, model, state, U, Rtab=None, flavour="vec"):

@@ -45,6 +45,29 @@ sys.path.insert(0, REF)
 warnings.filterwarnings("ignore")
 
 
+def scaler_arrays_from_raw_bytes(path, n_feat):
+    """(mean, var, scale, offsets) of a joblib-dumped StandardScaler, read as raw float64 payloads."""
+    b = open(path, "rb").read()
+
+    def arr_after(marker):
+        i = b.find(marker)
+        assert i >= 0, marker
+        j = b.find(b"numpy_array_alignment_bytes", i)
+        if j < 0 or j - i > 400:
+            j = i
+        for start in range(j, min(j + 200, len(b) - 8 * n_feat)):
+            vals = struct.unpack("<%dd" % n_feat, b[start:start + 8 * n_feat])
+            if all(np.isfinite(v) and 1e-12 < abs(v) < 1e12 for v in vals):
+                return start, np.array(vals)
+        raise AssertionError(marker)
+
+    o_mean, mean = arr_after(b"mean_")
+    o_var, var = arr_after(b"var_")
+    o_scale, scale = arr_after(b"scale_")
+    assert np.allclose(scale ** 2, var, rtol=1e-12), "scale^2 != var: wrong offsets"
+    return mean, var, scale, [o_mean, o_var, o_scale]
+
+
 def scaler_from_raw_bytes(path):
     b = open(path, "rb").read()
     n_feat = 18
@@ -291,6 +314,53 @@ def main():
         o2t = np.stack([np.broadcast_to(np.asarray(f(*c2), float), (128,)) for f in f2t])
         o2g = np.stack([np.broadcast_to(np.asarray(f(*c2), float), (128,)) for f in f2g])
     np.savez(f"{OUT}/kat_dynamics_gen2.npz", X=X2, out_theta=o2t, out_gamma=o2g)
+
+    # 11. generation 3: second-order models on the 14 named features of features_dd (main_fun.py:811-871),
+    #     outputs/dd_C6_all_50_s_20250511_013928/ (scaler.pkl read as raw bytes, 14 slots); names: dd_cluster.py:160-168 ("gama")
+    rng3 = np.random.default_rng(3)
+    D3 = f"{REF}/outputs/dd_C6_all_50_s_20250511_013928"
+    names3 = ["theta", "gama", "dtheta", "dgamma", "v_sway", "v_surge", "a_sway", "a_surge",
+              "V_x", "V_y", "V_z", "a_x", "a_y", "a_z"]
+    m3, v3, s3, off3 = scaler_arrays_from_raw_bytes(f"{D3}/scaler.pkl", 14)
+    json.dump({"n_features": 14, "variable_names": names3, "mean": m3.tolist(), "var": v3.tolist(), "scale": s3.tolist(),
+               "byte_offsets": off3, "source": "outputs/dd_C6_all_50_s_20250511_013928/scaler.pkl raw float64 payloads (not unpickled)"},
+              open(f"{OUT}/scaler_gen3.json", "w"), indent=1)
+    g3 = {"variable_names": names3}
+    for which, fn in (("ddtheta", "dtheta_results.csv"), ("ddgamma", "dgamma_results.csv")):
+        rows = []
+        with open(f"{D3}/{fn}") as f:
+            for r in csv.DictReader(f):
+                rows.append({"complexity": int(r["complexity"]), "loss": float(r["loss"]), "score": float(r["score"]),
+                             "equation": r["equation"], "sympy_format": r["sympy_format"]})
+        txt = open(f"{D3}/eq_{'dtheta_dt' if which == 'ddtheta' else 'dgamma_dt'}.txt").read()
+        g3[which] = {"chosen_complexity": int(txt.split("\n")[0].split()[-1]), "rows": rows}
+    json.dump(g3, open(f"{OUT}/equations_gen3.json", "w"), indent=1)
+    import sympy
+    syms3 = sympy.symbols(" ".join(names3))
+    X3 = rng3.normal(0, 1.2, (128, 14))                      # scaled rows, as the models see them (dd_cluster.py:212-216)
+    c3 = [X3[:, i] for i in range(14)]
+    outs3 = {}
+    for which in ("ddtheta", "ddgamma"):
+        fns = [sympy.lambdify(syms3, sympy.sympify(r["sympy_format"], locals=dict(zip(names3, syms3))), "numpy")
+               for r in g3[which]["rows"]]
+        with np.errstate(all="ignore"):
+            outs3[which] = np.stack([np.broadcast_to(np.asarray(f(*c3), float), (128,)) for f in fns])
+    np.savez(f"{OUT}/kat_dynamics_gen3.npz", X=X3, out_theta=outs3["ddtheta"], out_gamma=outs3["ddgamma"])
+    # features_dd itself (savgol window 11 / order 3, np.gradient chains, surge / sway) on a synthetic log
+    Td = 160
+    td = np.cumsum(rng3.uniform(0.03, 0.07, Td))
+    dfd = pd.DataFrame({"Time": td})
+    P0d = 1000 * np.stack([0.1 * np.sin(0.3 * td), 0.1 * np.cos(0.2 * td), 0.05 * td], 1) + rng3.normal(0, 2, (Td, 3))
+    P1d = P0d + 1000 * np.stack([0.6 + 0.2 * np.sin(0.5 * td), -0.4 + 0.1 * td, 0.3 * np.cos(0.4 * td)], 1)
+    Vd = np.stack([80 * np.sin(0.7 * td), 30 * np.cos(0.5 * td), 20 * np.sin(0.9 * td + 1)], 1) + rng3.normal(0, 3, (Td, 3))
+    for nm, arr in (("rod_end", P0d), ("robot_cable_attach_point", P1d), ("rob_cor_speed", Vd)):
+        for j, ax in enumerate("XYZ"):
+            dfd[f"{nm} {ax}"] = arr[:, j]
+    dfd["Theta"] = 0.3 * np.sin(0.8 * td) + rng3.normal(0, 0.01, Td)
+    dfd["Gamma"] = -0.2 * np.cos(0.6 * td) + rng3.normal(0, 0.01, Td)
+    Fd, Yd = main_fun.features_dd(dfd)
+    np.savez(f"{OUT}/kat_features_dd.npz", time=td, P0=P0d, P1=P1d, V=Vd, theta=dfd["Theta"].values, gamma=dfd["Gamma"].values,
+             features=Fd, targets=Yd)
 
     print("golden vectors written to", OUT)
 
