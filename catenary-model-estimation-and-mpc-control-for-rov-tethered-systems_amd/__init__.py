@@ -7,9 +7,9 @@ There is no CPU fallback: compute entry points raise ``RovmpcError`` without the
 """
 from ._lib import (RovmpcError, load_library, exported_symbols, LIB_PATH,
                    F64, F32, VT_NONE, VT_COMPOSE, VT_TABLE, PREV_INTERP, PREV_HOLD, RK4, EULER, DOUBLE_EULER, TRAPEZOID, ENU, NED,
-                   FEATURES_GEN1, FEATURES_GEN2)
+                   FEATURES_GEN1, FEATURES_GEN2, FEATURES_GEN3)
 from .expr import compile_expression, disassemble, ExpressionError, Program
-from .model import (DynamicsModel, default_model, generation2_model, load_model_dir, read_equation_csv, select_row,
+from .model import (DynamicsModel, default_model, generation2_model, generation3_model, FEATURE_NAMES_GEN3, load_model_dir, read_equation_csv, select_row,
                     chosen_complexity_from_txt, FEATURE_NAMES_GEN1)
 from .engine import Engine, MPCConfig, MPCState, StepResult, default_engine, state_array
 from .geometry import (rodrigues_rotation, transform_catenary, transform_catenary_batch, solve_catenary,

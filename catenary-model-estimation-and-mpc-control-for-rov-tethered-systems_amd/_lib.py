@@ -14,7 +14,7 @@ VT_NONE, VT_COMPOSE, VT_TABLE = 0, 1, 2
 PREV_INTERP, PREV_HOLD = 0, 1
 RK4, EULER, DOUBLE_EULER, TRAPEZOID = 0, 1, 2, 3
 ENU, NED = 0, 1
-FEATURES_GEN1, FEATURES_GEN2 = 0, 1
+FEATURES_GEN1, FEATURES_GEN2, FEATURES_GEN3 = 0, 1, 2
 STATE_LEN = 16
 
 ERR_NAMES = {0: "OK", -1: "ROVMPC_ERR_INVALID", -2: "ROVMPC_ERR_HIP", -3: "ROVMPC_ERR_NO_MODEL",

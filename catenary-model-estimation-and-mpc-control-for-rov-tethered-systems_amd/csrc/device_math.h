@@ -390,6 +390,13 @@ template <int SH> RV_DEV long long row_shl(long long v) {
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// features_dd (main_fun.py:842-843): v_surge = V . unit_rel, v_sway = |V x unit_rel|
+template <typename T> RV_DEV void dd_surge_sway(T vx, T vy, T vz, T ux, T uy, T uz, T &sway, T &surge) {
+    surge = vx * ux + vy * uy + vz * uz;
+    const T cx = vy * uz - vz * uy, cy = vz * ux - vx * uz, cz = vx * uy - vy * ux;
+    sway = m_sqrt(cx * cx + cy * cy + cz * cz);
+}
+
 // order-preserving double <-> int64 map (signed compare of keys == IEEE compare of values)
 RV_DEV long long ordered_key(double v) {
     long long b = __double_as_longlong(v);

@@ -29,6 +29,9 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 
 // Exogenous planes (0..13) the loaded expressions read.  A run-time argument for the interpreter;
 // the run-time generated translation unit defines it as a literal, so unused planes vanish there.
+#ifndef ROVMPC_JIT_FMAP
+#define ROVMPC_JIT_FMAP 0            // feature map of a hiprtc-specialised build (a literal there)
+#endif
 #ifndef ROVMPC_JIT_USED
 #define ROVMPC_JIT_USED 0xffffffffu
 #endif
@@ -45,7 +48,7 @@ constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + un
 // used.  Passing them by value as kernel arguments kept ~60 SGPRs live across the whole kernel
 // and pushed the sequential phase's loop into SGPR spills (v_writelane/v_readlane per step).
 template <typename T> struct RolloutConsts {
-    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up;
+    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up, vs;
     T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
     T Uref[3];
     T mean[18], inv_scale[18];
@@ -230,6 +233,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int N = a.N, CK = a.CK, K = a.K;
     const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
+    const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
     const RolloutConsts<T> &kk = *a.k;
     const int tid = threadIdx.x, NT = blockDim.x;
@@ -339,6 +343,40 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T nr = m_sqrt(rx * rx + ry * ry + rz * rz);
         const T inr = T(1) / (nr + T(1e-8));                                 // :26
         const T ux = rx * inr, uy = ry * inr, uz = rz * inr;
+        if (fmap == ROVMPC_FEATURES_GEN3) {
+            // features_dd (main_fun.py:839-864): plane p = scaled slot 4 + p =
+            // [v_sway, v_surge, a_sway, a_surge, V(3), a(3)], velocities in m/s
+            if (VT == ROVMPC_VT_COMPOSE) {       // V depends on (theta, gamma): rows are built beside the integration
+                RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
+                continue;
+            }
+            // the neighbour node of the first difference: n - 1, or node 1 for n = 0 (np.gradient's edge rule, :846-847)
+            const int m = n == 0 ? 1 : n - 1;
+            const T *um = &sU[c * US];
+            T Qx, Qy, Qz;                        // position of node m, bit-equal to its own sequential sum
+            if (n == 0) { Qx = Px + kk.vs_h * um[0]; Qy = Py + kk.vs_h * um[1]; Qz = Pz + kk.vs_h * um[2]; }
+            else {
+                Qx = (T)sd[3]; Qy = (T)sd[4]; Qz = (T)sd[5];
+                for (int j = 0; j < m; ++j) { Qx = Qx + kk.vs_h * um[3 * j]; Qy = Qy + kk.vs_h * um[3 * j + 1]; Qz = Qz + kk.vs_h * um[3 * j + 2]; }
+            }
+            T Vx, Vy, Vz, Wx, Wy, Wz;
+            vel(c, n, Vx, Vy, Vz); vel(c, m, Wx, Wy, Wz);
+            const T qx = Qx - P0x, qy = Qy - P0y, qz = Qz - P0z;
+            const T inq = T(1) / (m_sqrt(qx * qx + qy * qy + qz * qz) + T(1e-8));
+            T sway_n, surge_n, sway_m, surge_m;
+            dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, ux, uy, uz, sway_n, surge_n);
+            dd_surge_sway<T>(kk.vs * Wx, kk.vs * Wy, kk.vs * Wz, qx * inq, qy * inq, qz * inq, sway_m, surge_m);
+            const T sgn = n == 0 ? T(-1) : T(1);
+            const T a_sway = sgn * (sway_n - sway_m) * kk.inv_h, a_surge = sgn * (surge_n - surge_m) * kk.inv_h;
+            T Ax, Ay, Az;
+            if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
+            else { Ax = (Vx - Wx) * kk.inv_h; Ay = (Vy - Wy) * kk.inv_h; Az = (Vz - Wz) * kk.inv_h; }
+            const T row[10] = {sway_n, surge_n, a_sway, a_surge, kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, kk.vs * Ax, kk.vs * Ay, kk.vs * Az};
+#pragma unroll
+            for (int p = 0; p < 10; ++p)
+                if (uses(p)) RV_PL(sX, p, n, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
+            continue;
+        }
         const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
         if (uses(0)) RV_PL(sX, 0, n, c) = (Px - sMean[0]) * sInv[0];
         if (uses(1)) RV_PL(sX, 1, n, c) = (Py - sMean[1]) * sInv[1];
@@ -358,8 +396,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * kk.inv_h; Ay = (Vy - Wy) * kk.inv_h; Az = (Vz - Wz) * kk.inv_h; }
             const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
             T ap = (Vx * ux + Vy * uy + Vz * uz) / nv;
-            const int apslot = a.fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
-            if (a.fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
+            const int apslot = fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
+            if (fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
             if (uses(3)) RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
             if (uses(4)) RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
             if (uses(5)) RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
@@ -633,7 +671,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
             const bool euler = a.integrator == ROVMPC_EULER;
             const T hstep = kk.h, inv_hstep = kk.inv_h;
-            const bool gen2 = a.fmap == ROVMPC_FEATURES_GEN2;
+            const bool gen2 = fmap == ROVMPC_FEATURES_GEN2;
             const T hh = T(0.5) * hstep, h6 = hstep / T(6);
             // generic path: full 18-slot feature row per stage, bytecode interpreter
             T Vx = V0x, Vy = V0y, Vz = V0z;
@@ -737,8 +775,101 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
             }
         };
+        // Second-order generation (features_dd): y = (theta, gamma, dtheta, dgamma), y' = (dtheta, dgamma, f_theta(x), f_gamma(x)).
+        // Slots 0..3 of the row are the stage state, planes 0..9 the exogenous slots 4..13 (midpoint between nodes at
+        // the half stages, simulate_rk4_theta_gamma.py:62).  integrator EULER = the reference's explicit double Euler
+        // (test_cluster.py:113-129).  State slots 14/15 carry (dtheta, dgamma) at node 0.
+        auto integrate_dd = [&]() {
+            if (tid >= CK) return;
+            const int c = tid;
+            const int nsteps = (a.debug & 1) ? 0 : N;
+            T y0 = th0, y1 = ga0, y2 = thm0, y3 = gam0;
+            RV_PL(sY, 0, 0, c) = y0; RV_PL(sY, 1, 0, c) = y1;
+            const bool euler = a.integrator == ROVMPC_EULER;
+            const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * kk.h, h6 = kk.h / T(6);
+            T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
+            if (VT == ROVMPC_VT_COMPOSE)
+                dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
+            auto store_row = [&](int node, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
+                const T row[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
+#pragma unroll
+                for (int p = 0; p < 10; ++p)
+                    if (uses(p)) RV_PL(sX, p, node, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
+            };
+            T *feat = sF + c;
+            T *stack = sF + 18 * CK + c;
+            for (int n = 0; n < nsteps; ++n) {
+                if (VT == ROVMPC_VT_COMPOSE && (used & 0x3ffu)) {
+                    const V3<T> kt = {RV_PL(sA, 0, n, c), RV_PL(sA, 1, n, c), T(0)};
+                    const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+                    T st, ct, sg, cg;
+                    m_sincos(y0, &st, &ct); m_sincos(y1, &sg, &cg);
+                    const T *u = &sU[c * US + n * 3];
+                    V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    T sway_n, surge_n;
+                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, RV_PL(sA, 5, n + 1, c), RV_PL(sA, 6, n + 1, c), RV_PL(sA, 7, n + 1, c), sway_n, surge_n);
+                    const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
+                    if (n == 0) store_row(0, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);
+                    store_row(n + 1, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
+                              (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
+                    Vx = v.x; Vy = v.y; Vz = v.z; sway_p = sway_n; surge_p = surge_n;
+                }
+                auto stage = [&](T s0, T s1, T s2, T s3, int cfrac2, T &ddth, T &ddga) {
+                    if (MODEL == MODEL_JIT) {
+                        T x[18];
+#pragma unroll
+                        for (int p = 0; p < 10; ++p) {
+                            if (cfrac2 == 0) x[4 + p] = RV_PL(sX, p, n, c);
+                            else if (cfrac2 == 2) x[4 + p] = RV_PL(sX, p, n + 1, c);
+                            else x[4 + p] = (RV_PL(sX, p, n, c) + RV_PL(sX, p, n + 1, c)) / T(2);
+                        }
+                        x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
+                        x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
+                        x[14] = x[15] = x[16] = x[17] = T(0);
+                        ddth = jit_f_theta<T>(x);
+                        ddga = jit_f_gamma<T>(x);
+                        return;
+                    }
+                    for (int p = 0; p < 10; ++p) {
+                        if (!uses(p)) continue;
+                        T v;
+                        if (cfrac2 == 0) v = RV_PL(sX, p, n, c);
+                        else if (cfrac2 == 2) v = RV_PL(sX, p, n + 1, c);
+                        else v = (RV_PL(sX, p, n, c) + RV_PL(sX, p, n + 1, c)) / T(2);
+                        feat[(4 + p) * CK] = v;
+                    }
+                    feat[0] = (s0 - sMean[0]) * sInv[0]; feat[CK] = (s1 - sMean[1]) * sInv[1];
+                    feat[2 * CK] = (s2 - sMean[2]) * sInv[2]; feat[3 * CK] = (s3 - sMean[3]) * sInv[3];
+                    ddth = interp_eval<T>(a.code_th, a.n_th, a.consts, feat, CK, stack, CK);
+                    ddga = interp_eval<T>(a.code_ga, a.n_ga, a.consts, feat, CK, stack, CK);
+                };
+                T a1t, a1g;
+                stage(y0, y1, y2, y3, 0, a1t, a1g);
+                if (euler) {
+                    const T n0 = y0 + y2 * hstep, n1 = y1 + y3 * hstep;            // test_cluster.py:125-129
+                    y2 = y2 + a1t * hstep; y3 = y3 + a1g * hstep;                    // :113-117
+                    y0 = n0; y1 = n1;
+                } else {
+                    // k_i = (rate_i, acc_i); rates at the stage states
+                    const T r1t = y2, r1g = y3;
+                    const T r2t = y2 + hh * a1t, r2g = y3 + hh * a1g;
+                    T a2t, a2g, a3t, a3g, a4t, a4g;
+                    stage(y0 + hh * r1t, y1 + hh * r1g, r2t, r2g, 1, a2t, a2g);
+                    const T r3t = y2 + hh * a2t, r3g = y3 + hh * a2g;
+                    stage(y0 + hh * r2t, y1 + hh * r2g, r3t, r3g, 1, a3t, a3g);
+                    const T r4t = y2 + hstep * a3t, r4g = y3 + hstep * a3g;
+                    stage(y0 + hstep * r3t, y1 + hstep * r3g, r4t, r4g, 2, a4t, a4g);
+                    y0 = y0 + h6 * (r1t + T(2) * r2t + T(2) * r3t + r4t);
+                    y1 = y1 + h6 * (r1g + T(2) * r2g + T(2) * r3g + r4g);
+                    y2 = y2 + h6 * (a1t + T(2) * a2t + T(2) * a3t + a4t);
+                    y3 = y3 + h6 * (a1g + T(2) * a2g + T(2) * a3g + a4g);
+                }
+                RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
+            }
+        };
         const bool wide = NT > nint;
-        if (tid < nint) integrate();
+        if (tid < nint) { if (fmap == ROVMPC_FEATURES_GEN3) integrate_dd(); else integrate(); }
         if (!wide || tid >= nint) geometry_a(-1, wide ? tid - nint : tid, wide ? NT - nint : NT, 0);
     }
     __syncthreads();

@@ -225,7 +225,7 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     if (cfg->prev_mode < 0 || cfg->prev_mode > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad prev_mode %d", cfg->prev_mode);
     if (cfg->integrator < 0 || cfg->integrator > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad integrator %d", cfg->integrator);
     if (cfg->frame < 0 || cfg->frame > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad frame %d", cfg->frame);
-    if (cfg->feature_map < 0 || cfg->feature_map > 1) FAIL(nullh, ROVMPC_ERR_INVALID, "bad feature_map %d", cfg->feature_map);
+    if (cfg->feature_map < 0 || cfg->feature_map > 2) FAIL(nullh, ROVMPC_ERR_INVALID, "bad feature_map %d", cfg->feature_map);
     if (!(cfg->dt > 0) || !(cfg->L > 0) || !(cfg->c_lo > 0) || !(cfg->c_hi > cfg->c_lo))
         FAIL(nullh, ROVMPC_ERR_INVALID, "dt, L must be > 0 and 0 < c_lo < c_hi");
     if (cfg->candidates_per_block < 0 || cfg->candidates_per_block > 64 ||
@@ -308,7 +308,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
 
 template <typename T> static void fill_consts(const rovmpc_handle *h, RolloutConsts<T> &k) {
     const rovmpc_config &c = h->cfg;
-    k.h = (T)c.dt; k.vs_h = (T)(c.v_scale * c.dt); k.inv_h = (T)(1.0 / c.dt); k.L = (T)c.L;
+    k.h = (T)c.dt; k.vs_h = (T)(c.v_scale * c.dt); k.vs = (T)c.v_scale; k.inv_h = (T)(1.0 / c.dt); k.L = (T)c.L;
     k.w_per_len = (T)(c.cable_wet_weight / c.L); k.c_lo = (T)c.c_lo; k.c_hi = (T)c.c_hi;
     k.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
     k.w_theta = (T)c.w_theta; k.w_gamma = (T)c.w_gamma; k.w_u = (T)c.w_u; k.w_T = (T)c.w_T;
@@ -418,6 +418,7 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
                               const double *consts) {
     const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
     std::string s;
+    s += "#define ROVMPC_JIT_FMAP " + std::to_string(h->cfg.feature_map) + "\n";
     s += "#define ROVMPC_JIT_USED " + std::to_string(h->used_planes) + "u\n#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
     s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
     s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
@@ -555,6 +556,7 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
                 if ((code[pc] & 0xff) == ROVMPC_OP_PUSH_F) {
                     const int f = code[pc] >> 8;
                     if (h->cfg.feature_map == ROVMPC_FEATURES_GEN2) { if (f < 12) m |= 1u << f; else if (f == 16) m |= 1u << 13; }
+                    else if (h->cfg.feature_map == ROVMPC_FEATURES_GEN3) { if (f >= 4 && f < 14) m |= 1u << (f - 4); }   // plane p = slot 4 + p
                     else if (f < 14) m |= 1u << f;
                 }
         };
@@ -665,9 +667,9 @@ template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h,
 
 static int check_ready(rovmpc_handle *h) {
     if (!h->has_model) FAIL(h, ROVMPC_ERR_NO_MODEL, "rovmpc_set_model has not been called");
-    const int want = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 17 : 18;
+    const int want = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 17 : h->cfg.feature_map == ROVMPC_FEATURES_GEN3 ? 14 : 18;
     if (h->n_feat != want)
-        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "feature_map %d has %d slots (simply.py:15-41 / simulate_rk4_theta_gamma.py:12-42) but the model has %d",
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "feature_map %d has %d slots (simply.py:15-41 / simulate_rk4_theta_gamma.py:12-42 / main_fun.py:849-864) but the model has %d",
              h->cfg.feature_map, want, h->n_feat);
     if (h->cfg.vt_mode == ROVMPC_VT_TABLE && !h->has_rtab) FAIL(h, ROVMPC_ERR_INVALID, "vt_mode TABLE needs rovmpc_set_rotation_table");
     return ROVMPC_OK;

@@ -31,6 +31,7 @@ class DynamicsModel:
     consts: List[float] = field(default_factory=list)
     prog_theta: Optional[Program] = None
     prog_gamma: Optional[Program] = None
+    variable_names: Optional[Sequence[str]] = None     # PySR variable_names (dd_cluster.py:160-168); x0..xN always work
 
     def __post_init__(self):
         self.mean = np.ascontiguousarray(self.mean, dtype=np.float64)
@@ -39,8 +40,8 @@ class DynamicsModel:
             raise ValueError("mean and scale must be 1-D arrays of equal length")
         n = self.n_features
         self.consts = []
-        self.prog_theta = compile_expression(self.expr_theta, self.consts, n)
-        self.prog_gamma = compile_expression(self.expr_gamma, self.consts, n)
+        self.prog_theta = compile_expression(self.expr_theta, self.consts, n, self.variable_names)
+        self.prog_gamma = compile_expression(self.expr_gamma, self.consts, n, self.variable_names)
 
     @property
     def n_features(self) -> int:
@@ -118,3 +119,24 @@ def generation2_model(complexity_theta: Optional[int] = None, complexity_gamma: 
     m.expr_gamma = select_row(e["dgamma_dt"]["rows"], cg)["sympy_format"]
     m.__post_init__()
     return m
+
+
+# dd_cluster.py:160-168 -- variable_names of the second-order runs ("gama": sympy reserves gamma)
+FEATURE_NAMES_GEN3 = ["theta", "gama", "dtheta", "dgamma", "v_sway", "v_surge", "a_sway", "a_surge",
+                      "V_x", "V_y", "V_z", "a_x", "a_y", "a_z"]
+
+
+def generation3_model(complexity_theta: Optional[int] = None, complexity_gamma: Optional[int] = None) -> DynamicsModel:
+    """Second-order model generation (dd_cluster.py): (ddtheta, ddgamma) = f(scaled features_dd row),
+    14 named features (main_fun.py:849-864), rows of outputs/dd_C6_all_50_s_20250511_013928/
+    d{theta,gamma}_results.csv named by eq_*.txt:1 (complexity 6 / 5), that run's scaler.
+    Use with ``MPCConfig(feature_map=FEATURES_GEN3)``; ``MPCState.theta_prev / gamma_prev`` carry the
+    angular rates (dtheta, dgamma) in this map."""
+    s = json.load(open(os.path.join(DATA_DIR, "gen3_scaler.json")))
+    e = json.load(open(os.path.join(DATA_DIR, "gen3_equations.json")))
+    ct = complexity_theta or e["ddtheta"]["chosen_complexity"]
+    cg = complexity_gamma or e["ddgamma"]["chosen_complexity"]
+    return DynamicsModel(np.array(s["mean"]), np.array(s["scale"]),
+                         select_row(e["ddtheta"]["rows"], ct)["sympy_format"],
+                         select_row(e["ddgamma"]["rows"], cg)["sympy_format"],
+                         variable_names=e.get("variable_names", FEATURE_NAMES_GEN3))

@@ -68,9 +68,16 @@ extern "C" {
  * GEN1: 18 slots [P1, V1, A1, unit_rel, tension, angle_proj, theta, gamma, theta_prev, gamma_prev],
  *       StandardScaler-normalised (simply.py:15-41, saved_models/);
  * GEN2: 17 slots [P1, V1, A1, unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj(unclipped)],
- *       unscaled (simulate_rk4_theta_gamma.py:12-42, outputs/differential_training_new_feature/). */
+ *       unscaled (simulate_rk4_theta_gamma.py:12-42, outputs/differential_training_new_feature/);
+ * GEN3: 14 slots [theta, gamma, dtheta, dgamma, v_sway, v_surge, a_sway, a_surge, V(3), a(3)] (features_dd,
+ *       main_fun.py:811-871; V in m/s), StandardScaler-normalised; the expressions are SECOND derivatives
+ *       (ddtheta, ddgamma -- dd_cluster.py, outputs/dd_C6_all_50_s_20250511_013928/).  The rollout integrates
+ *       y = (theta, gamma, dtheta, dgamma), y' = (dtheta, dgamma, f_theta, f_gamma) with RK4, or with the
+ *       reference's explicit double Euler (test_cluster.py:110-129) when integrator = ROVMPC_EULER;
+ *       rovmpc_state.theta_prev / gamma_prev carry dtheta / dgamma at node 0 in this map. */
 #define ROVMPC_FEATURES_GEN1 0
 #define ROVMPC_FEATURES_GEN2 1
+#define ROVMPC_FEATURES_GEN3 2
 
 #define ROVMPC_MAX_FEATURES 32
 #define ROVMPC_MAX_CODE     256
@@ -108,7 +115,7 @@ typedef struct rovmpc_config {
     int32_t candidates_per_block; /* 0 = auto; else a power of two <= 64                    */
     int32_t debug_flags;        /* diagnostics only (phase ablation for profiling); keep 0  */
     int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
-    int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | ROVMPC_FEATURES_GEN2              */
+    int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | _GEN2 | _GEN3                     */
     int32_t threads_per_block;  /* 0 = auto; else a multiple of 64 in 64..512                */
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */

@@ -349,6 +349,68 @@ def test_generation2_feature_map(rv, orc, jit, vt_mode):
             e.step(state, U[:8, :4])
 
 
+@pytest.mark.parametrize("jit", [True, False])
+@pytest.mark.parametrize("vt_mode,integrator", [(0, 0), (1, 0), (2, 0), (1, 1), (0, 1)])
+def test_generation3_second_order_rollout(rv, orc, jit, vt_mode, integrator):
+    """Second-order models (dd_cluster.py; rows 6 / 5 of outputs/dd_C6_all_50_s_20250511_013928/) on the 14 named
+    features of features_dd: state (theta, gamma, dtheta, dgamma), RK4 and the reference's double Euler."""
+    model = rv.generation3_model()
+    cfg = rv.MPCConfig(N=12, K=80, feature_map=rv.FEATURES_GEN3, jit=jit, vt_mode=vt_mode, integrator=integrator)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, 20250523)
+    state[14], state[15] = 0.013, -0.021                       # dtheta_0, dgamma_0
+    state[9:12] = (5.0, -3.0, 2.0)
+    Rtab = rand_rtab(cfg.N) if vt_mode == 2 else None
+    with rv.Engine(cfg, model) as e:
+        assert e.model_path == ("jit" if jit else "interpreter")
+        if Rtab is not None:
+            e.set_rotation_table(Rtab)
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+        res = e.step(state, U)
+    om = orc.DynamicsModel(model.mean, model.scale, orc.SymbolicModel(model.expr_theta, 14, model.variable_names),
+                           orc.SymbolicModel(model.expr_gamma, 14, model.variable_names))
+    Jo, trajo, _ = orc.rollout_vec_dd(oracle_cfg(orc, cfg), om, orc.MPCState.from_array(state), U, Rtab)
+    np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(J, Jo, rtol=1e-8)
+    k = int(np.argmin(Jo))
+    assert res.index == k and np.array_equal(res.u, U[k, 0])
+    np.testing.assert_allclose(res.traj, trajo[k], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("ct,cg", [(9, 8), (14, 9), (22, 18), (4, 16)])
+def test_generation3_other_rows(rv, orc, ct, cg):
+    """Other Pareto rows of the second-order run (division by V_x, nested sin, the 'gama' variable)."""
+    model = rv.generation3_model(ct, cg)
+    cfg = rv.MPCConfig(N=8, K=48, feature_map=rv.FEATURES_GEN3)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, 3)
+    state[14], state[15] = -0.02, 0.03
+    with rv.Engine(cfg, model) as e:
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+    om = orc.DynamicsModel(model.mean, model.scale, orc.SymbolicModel(model.expr_theta, 14, model.variable_names),
+                           orc.SymbolicModel(model.expr_gamma, 14, model.variable_names))
+    Jo, trajo, _ = orc.rollout_vec_dd(oracle_cfg(orc, cfg), om, orc.MPCState.from_array(state), U)
+    ok = np.isfinite(Jo)
+    assert ok.sum() > cfg.K // 2
+    np.testing.assert_allclose(traj[ok], trajo[ok], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(J[ok], Jo[ok], rtol=1e-7)
+
+
+def test_generation3_predict_matches_reference_rows(rv, golden_dir):
+    """Every row of the second-order Pareto fronts through rovmpc_predict vs sympy-lambdified reference text."""
+    import json
+    g = np.load(os.path.join(golden_dir, "kat_dynamics_gen3.npz"))
+    eq = json.load(open(os.path.join(golden_dir, "equations_gen3.json")))
+    sc = json.load(open(os.path.join(golden_dir, "scaler_gen3.json")))
+    for which, key in (("ddtheta", "out_theta"), ("ddgamma", "out_gamma")):
+        for i, r in enumerate(eq[which]["rows"]):
+            m = rv.DynamicsModel(np.zeros(14), np.ones(14), r["sympy_format"], "0.0*theta", variable_names=eq["variable_names"])
+            with rv.Engine(rv.MPCConfig(N=2, K=2, feature_map=rv.FEATURES_GEN3), m) as e:
+                out_t = e.predict(g["X"], 0)
+            ref = g[key][i]
+            fin = np.isfinite(ref)
+            np.testing.assert_allclose(out_t[fin], ref[fin], rtol=1e-10, atol=1e-13)
+    assert len(sc["mean"]) == 14
+
+
 def test_rollout_c3_fp32(rv, orc):
     """BASELINE config 3: N=50, K=16384 in fp32, checked against the fp64 oracle with the rule of
     SURVEY section 8(d): same k*, or |J32 - J64| / J64 < 1e-4 at both minimisers."""

@@ -223,3 +223,18 @@ def test_state_and_shape_validation():
         rovmpc.MPCConfig(dtype="f16").to_c()
     st, U = rovmpc.synthetic_problem(8, 5)
     assert st.shape == (16,) and U.shape == (8, 5, 3)
+
+
+def test_generation3_model_compiles_named_variables():
+    """dd_cluster.py:160-168 variable names ('gama'), 14-slot scaler of the second-order run."""
+    import rovmpc
+    m = rovmpc.generation3_model()
+    assert m.n_features == 14 and m.variable_names[1] == "gama"
+    assert m.expr_theta == "dtheta*sin(a_surge + 0.6155493)"
+    assert "a_x" in m.expr_gamma and "a_y" in m.expr_gamma
+    txt = rovmpc.disassemble(m.prog_theta, m.consts)
+    assert "x2" in txt and "x7" in txt                         # dtheta = slot 2, a_surge = slot 7
+    m2 = rovmpc.generation3_model(4, 16)                       # a row that uses 'gama'
+    assert "x1" in rovmpc.disassemble(m2.prog_gamma, m2.consts)
+    with pytest.raises(rovmpc.ExpressionError):
+        rovmpc.DynamicsModel(np.zeros(14), np.ones(14), "gamma_typo*2", "theta", variable_names=rovmpc.FEATURE_NAMES_GEN3)

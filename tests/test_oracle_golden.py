@@ -257,3 +257,62 @@ def test_generation2_scalar_and_vector_rollouts_agree(golden_dir):
     Jv, tv, _ = orc.rollout_vec(cfg, model, st, U)
     np.testing.assert_allclose(tv, ts, rtol=1e-11, atol=1e-14)
     np.testing.assert_allclose(Jv, Js, rtol=1e-10)
+
+
+# ---- second-order generation (features_dd, dd_cluster.py) -----------------------------------
+
+def _gen3(golden_dir):
+    import json
+    eq = json.load(open(os.path.join(golden_dir, "equations_gen3.json")))
+    sc = json.load(open(os.path.join(golden_dir, "scaler_gen3.json")))
+    return eq, np.array(sc["mean"]), np.array(sc["scale"])
+
+
+def test_features_dd_equal_the_reference(golden_dir):
+    """oracle.features_dd vs main_fun.features_dd run on the same synthetic log (savgol 11/3, gradient chains)."""
+    d = np.load(os.path.join(golden_dir, "kat_features_dd.npz"))
+    F, Y = orc.features_dd(d["P0"], d["P1"], d["V"], d["time"], d["theta"], d["gamma"])
+    np.testing.assert_allclose(F, d["features"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Y, d["targets"], rtol=1e-12, atol=1e-14)
+
+
+def test_generation3_rows_named_variables(golden_dir):
+    eq, mean, scale = _gen3(golden_dir)
+    assert eq["variable_names"][1] == "gama" and len(mean) == 14           # dd_cluster.py:160-168
+    assert eq["ddtheta"]["chosen_complexity"] == 6 and eq["ddgamma"]["chosen_complexity"] == 5
+    g = np.load(os.path.join(golden_dir, "kat_dynamics_gen3.npz"))
+    for which, key in (("ddtheta", "out_theta"), ("ddgamma", "out_gamma")):
+        for i, row in enumerate(eq[which]["rows"]):
+            m = orc.SymbolicModel(row["sympy_format"], 14, eq["variable_names"])
+            np.testing.assert_allclose(m.predict(g["X"]), g[key][i], rtol=1e-13, atol=1e-16)
+
+
+@pytest.mark.parametrize("vt_mode,integrator", [(0, 0), (1, 0), (1, 1), (2, 0)])
+def test_second_order_rollout_scalar_equals_vectorised(golden_dir, vt_mode, integrator):
+    eq, mean, scale = _gen3(golden_dir)
+    pick = lambda w: [r for r in eq[w]["rows"] if r["complexity"] == eq[w]["chosen_complexity"]][0]["sympy_format"]  # noqa: E731
+    model = orc.DynamicsModel(mean, scale, orc.SymbolicModel(pick("ddtheta"), 14, eq["variable_names"]),
+                              orc.SymbolicModel(pick("ddgamma"), 14, eq["variable_names"]))
+    rng = np.random.default_rng(5)
+    K, N = 5, 9
+    U = np.array([80.85, -20.13, -18.35]) + np.array([108.49, 15.88, 63.13]) * rng.standard_normal((K, N, 3))
+    st = orc.MPCState(np.zeros(3), np.array([0.2435, -0.7583, 0.2980]), np.array([80.85, -20.13, -18.35]),
+                      np.array([5., -3., 2.]), -0.0342, -0.0522, 0.01, -0.02)
+    Rtab = None
+    if vt_mode == 2:
+        Rtab = np.stack([np.linalg.qr(rng.standard_normal((3, 3)))[0] for _ in range(N)])
+    cfg = orc.MPCConfig(N=N, dt=1 / 60, vt_mode=vt_mode, integrator=integrator, feature_map=2)
+    J, traj, aux = orc.rollout_vec_dd(cfg, model, st, U, Rtab)
+    ts = orc.rollout_scalar_dd(cfg, model, st, U, Rtab)
+    np.testing.assert_allclose(traj, ts, rtol=1e-12, atol=1e-15)
+    assert np.all(np.isfinite(J))
+    # double Euler of the reference on a frozen input equals its open-loop replay (test_cluster.py:110-129)
+    if integrator == 1 and vt_mode == 0:
+        zero = orc.DynamicsModel(mean, scale, orc.SymbolicModel("0.25 + 0*theta", 14, eq["variable_names"]),
+                                 orc.SymbolicModel("-0.5 + 0*theta", 14, eq["variable_names"]))
+        _, tz, _ = orc.rollout_vec_dd(cfg, zero, st, U[:1])
+        t = np.arange(N + 1) * cfg.dt
+        th, ga = orc.double_euler_replay(np.full(N + 1, 0.25), np.full(N + 1, -0.5), t, st.theta, st.gamma)
+        # the replay starts from zero rates (test_cluster.py:111-112); add the initial-rate ramp
+        np.testing.assert_allclose(tz[0, :, 0], th + st.theta_prev * t, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(tz[0, :, 1], ga + st.gamma_prev * t, rtol=1e-12, atol=1e-15)
