@@ -1013,6 +1013,73 @@ extern "C" int rovmpc_extract_features(rovmpc_handle *h, const double *P0, const
     return ROVMPC_OK;
 }
 
+// Hat matrix of the least-squares polynomial fit of degree `order` on `window` equally spaced samples
+// (centred abscissae): H = Q Q^T with Q the orthonormalised monomials (modified Gram-Schmidt, twice).
+static void savgol_hat_matrix(int window, int order, std::vector<double> &H) {
+    const int w = window, m = order + 1, half = w / 2;
+    std::vector<long double> Q((size_t)w * m);
+    for (int c = 0; c < m; ++c) {
+        for (int r = 0; r < w; ++r) Q[(size_t)r * m + c] = powl((long double)(r - half), c);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int p = 0; p < c; ++p) {
+                long double d = 0;
+                for (int r = 0; r < w; ++r) d += Q[(size_t)r * m + c] * Q[(size_t)r * m + p];
+                for (int r = 0; r < w; ++r) Q[(size_t)r * m + c] -= d * Q[(size_t)r * m + p];
+            }
+        long double n = 0;
+        for (int r = 0; r < w; ++r) n += Q[(size_t)r * m + c] * Q[(size_t)r * m + c];
+        n = sqrtl(n);
+        for (int r = 0; r < w; ++r) Q[(size_t)r * m + c] /= n;
+    }
+    H.assign((size_t)w * w, 0.0);
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < w; ++j) {
+            long double s = 0;
+            for (int c = 0; c < m; ++c) s += Q[(size_t)i * m + c] * Q[(size_t)j * m + c];
+            H[(size_t)i * w + j] = (double)s;
+        }
+}
+
+extern "C" int rovmpc_features_dd(rovmpc_handle *h, const double *P0_mm, const double *P1_mm, const double *V_mm, const double *time,
+                                  const double *theta, const double *gamma, int64_t T, int32_t window, int32_t polyorder,
+                                  double *features, double *targets) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!P0_mm || !P1_mm || !V_mm || !time || !theta || !gamma || !features)
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_features_dd: null argument");
+    if (window < 3 || window > 255 || window % 2 == 0 || polyorder < 0 || polyorder >= window)
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_features_dd: window must be odd in 3..255 and polyorder < window (got %d, %d)", window, polyorder);
+    if (T < window) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_features_dd: %lld rows, fewer than the smoothing window %d (savgol_filter mode='interp')", (long long)T, window);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    std::vector<double> H;
+    savgol_hat_matrix(window, polyorder, H);
+    DevBuf d0, d1, dv, dt, dth, dga, dW, dF, dY, dpairs;
+    UPLOAD(h, d0, P0_mm, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, d1, P1_mm, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, dv, V_mm, (size_t)T * 3 * sizeof(double));
+    UPLOAD(h, dt, time, (size_t)T * sizeof(double));
+    UPLOAD(h, dth, theta, (size_t)T * sizeof(double));
+    UPLOAD(h, dga, gamma, (size_t)T * sizeof(double));
+    UPLOAD(h, dW, H.data(), H.size() * sizeof(double));
+    // pass 2: [dtheta, dgamma, a_sway, a_surge, a_x, a_y, a_z] <- gradients of pass-1 columns (main_fun.py:825-847);
+    // pass 3: targets [ddtheta, ddgamma] <- gradients of columns 2, 3 (:835-836)
+    const int pairs[] = {0, 2, 1, 3, 4, 6, 5, 7, 8, 11, 9, 12, 10, 13, /* pass 3 */ 2, 0, 3, 1};
+    UPLOAD(h, dpairs, pairs, sizeof(pairs));
+    HIPCHK(h, dF.alloc((size_t)T * 14 * sizeof(double)));
+    HIPCHK(h, dY.alloc((size_t)T * 2 * sizeof(double)));
+    const dim3 grid(grid_for(T, 256)), block(256);
+    hipLaunchKernelGGL(features_dd_pass1_kernel, grid, block, 0, h->stream, d0.as<double>(), d1.as<double>(), dv.as<double>(),
+                       dth.as<double>(), dga.as<double>(), dW.as<double>(), window, (long long)T, dF.as<double>());
+    hipLaunchKernelGGL(gradient_columns_kernel, grid, block, 0, h->stream, (const double *)dF.as<double>(), 14, dF.as<double>(), 14,
+                       dt.as<double>(), (long long)T, 7, (const int *)dpairs.p);
+    hipLaunchKernelGGL(gradient_columns_kernel, grid, block, 0, h->stream, (const double *)dF.as<double>(), 14, dY.as<double>(), 2,
+                       dt.as<double>(), (long long)T, 2, (const int *)dpairs.p + 14);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(features, dF.p, (size_t)T * 14 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (targets) HIPCHK(h, hipMemcpyAsync(targets, dY.p, (size_t)T * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_kabsch_velocity_transform(rovmpc_handle *h, const double *P, const double *Q, const double *v, int64_t T,
                                                 int32_t M, int32_t batch_gates, double *v_out, double *R_out) {
     if (!h) return ROVMPC_ERR_INVALID;

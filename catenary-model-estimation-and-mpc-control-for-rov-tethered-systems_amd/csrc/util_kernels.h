@@ -264,6 +264,44 @@ extract_features_kernel(const double *__restrict__ P0, const double *__restrict_
     if (with_prev) { o[16] = theta[i > 0 ? i - 1 : 0]; o[17] = gamma[i > 0 ? i - 1 : 0]; }   // :35-38
 }
 
+// features_dd (main_fun.py:811-871), pass 1 of 3, one lane per row.  W = window x window hat matrix of the
+// Savitzky-Golay polynomial fit (host-built): interior rows use its centre row, the first / last half-window
+// rows the polynomial fitted to the first / last `window` samples (scipy savgol_filter, mode='interp').
+// Writes feature columns 0,1 (smoothed theta, gamma), 4,5 (v_sway, v_surge), 8..10 (V in m/s) of out[T][14].
+__global__ void __launch_bounds__(256)
+features_dd_pass1_kernel(const double *__restrict__ P0mm, const double *__restrict__ P1mm, const double *__restrict__ Vmm,
+                         const double *__restrict__ theta, const double *__restrict__ gamma, const double *__restrict__ W,
+                         int window, long long T, double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int half = window / 2;
+    long long first; int row;
+    if (i < half) { first = 0; row = (int)i; }
+    else if (i >= T - half) { first = T - window; row = (int)(i - first); }
+    else { first = i - half; row = half; }
+    const double *w = W + (size_t)row * window;
+    double st = 0.0, sg = 0.0;
+    for (int j = 0; j < window; ++j) { st += w[j] * theta[first + j]; sg += w[j] * gamma[first + j]; }
+    double *o = out + i * 14;
+    o[0] = st; o[1] = sg;                                                                    // :830-831
+    const double vx = Vmm[3 * i] / 1000, vy = Vmm[3 * i + 1] / 1000, vz = Vmm[3 * i + 2] / 1000;   // :815
+    const double rx = P1mm[3 * i] / 1000 - P0mm[3 * i] / 1000, ry = P1mm[3 * i + 1] / 1000 - P0mm[3 * i + 1] / 1000,
+                 rz = P1mm[3 * i + 2] / 1000 - P0mm[3 * i + 2] / 1000;                       // :813-814, :839
+    const double nr = m_sqrt(rx * rx + ry * ry + rz * rz) + 1e-8;                            // :841
+    dd_surge_sway<double>(vx, vy, vz, rx / nr, ry / nr, rz / nr, o[4], o[5]);                // :842-843
+    o[8] = vx; o[9] = vy; o[10] = vz;
+}
+
+// passes 2 and 3: np.gradient of `npairs` columns of a [T][ld_src] table into columns of a [T][ld_dst] table.
+__global__ void __launch_bounds__(256)
+gradient_columns_kernel(const double *__restrict__ src, int ld_src, double *__restrict__ dst, int ld_dst,
+                        const double *__restrict__ time, long long T, int npairs, const int *__restrict__ pairs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    for (int p = 0; p < npairs; ++p)
+        dst[i * ld_dst + pairs[2 * p + 1]] = np_gradient(src + pairs[2 * p], time, i, T, ld_src);
+}
+
 // compute_rotation_kabsch (velocity_transform_batch.py:8-19) + the per-frame gates of :75-101,
 // one lane per frame.  H = Pc^T Qc = U S V^T; R = V U^T with the reflection fix.  A proper
 // rotation that maps u1 -> v1 and u2 -> v2 is unique, so R needs only the two dominant singular

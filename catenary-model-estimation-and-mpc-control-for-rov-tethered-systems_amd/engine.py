@@ -341,6 +341,20 @@ class Engine:
                                                      _ptr(gamma), T, int(with_prev), _ptr(out)))
         return out
 
+    def features_dd(self, P0_mm, P1_mm, V_mm, time, theta, gamma, window: int = 11, polyorder: int = 3):
+        """main_fun.py:811-871 on arrays as logged (mm, mm/s): returns (features (T,14), targets (T,2))."""
+        c = lambda x, shape: np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), shape))
+        time = np.ascontiguousarray(time, np.float64).reshape(-1)
+        T = time.shape[0]
+        if T < window:
+            raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")   # scipy's message
+        P0, P1, V = c(P0_mm, (T, 3)), c(P1_mm, (T, 3)), c(V_mm, (T, 3))
+        theta, gamma = c(np.asarray(theta, np.float64).reshape(-1), (T,)), c(np.asarray(gamma, np.float64).reshape(-1), (T,))
+        F = np.empty((T, 14)); Y = np.empty((T, 2))
+        self._check(self.lib.rovmpc_features_dd(self._h, _ptr(P0), _ptr(P1), _ptr(V), _ptr(time), _ptr(theta), _ptr(gamma),
+                                                T, window, polyorder, _ptr(F), _ptr(Y)))
+        return F, Y
+
     def kabsch_velocity_transform(self, P, Q, v, batch_gates: bool = True):
         P = np.ascontiguousarray(P, np.float64); Q = np.ascontiguousarray(Q, np.float64)
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3)

@@ -40,3 +40,17 @@ def extract_features(df, with_prev: bool = True) -> np.ndarray:
     P1 = df[["robot_cable_attach_point X", "robot_cable_attach_point Y", "robot_cable_attach_point Z"]].values / 1000
     V1 = df[["rob_cor_speed X", "rob_cor_speed Y", "rob_cor_speed Z"]].values
     return extract_features_arrays(P0, P1, V1, df["Time"].values, df["Theta"].values, df["Gamma"].values, with_prev)
+
+
+def features_dd_arrays(P0_mm, P1_mm, V_mm, time, theta, gamma, window: int = 11, polyorder: int = 3):
+    """features_dd on arrays as logged (mm, mm/s).  GPU.  Returns (features (T,14), targets (T,2))."""
+    from .engine import default_engine
+    return default_engine().features_dd(P0_mm, P1_mm, V_mm, time, theta, gamma, window, polyorder)
+
+
+def features_dd(df):
+    """Same signature and column names as main_fun.py:811 -- returns (features, targets) of the second-order runs."""
+    P0 = df[["rod_end X", "rod_end Y", "rod_end Z"]].values
+    P1 = df[["robot_cable_attach_point X", "robot_cable_attach_point Y", "robot_cable_attach_point Z"]].values
+    V1 = df[["rob_cor_speed X", "rob_cor_speed Y", "rob_cor_speed Z"]].values
+    return features_dd_arrays(P0, P1, V1, df["Time"].values, df["Theta"].values, df["Gamma"].values)

@@ -275,11 +275,21 @@ int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B
 int rovmpc_velocity_transform(rovmpc_handle *h, const double *R, const double *v,
                               int64_t n, double *out);
 
+/* features_dd (main_fun.py:811-871), the feature / target table of the second-order runs, for T rows of a log:
+ * P0_mm, P1_mm, V_mm [T][3] as logged (mm, mm/s: the map divides by 1000), time [T], raw theta, gamma [T] ->
+ * features[T][14] = [savgol(theta), savgol(gamma), their np.gradient, v_sway, v_surge, np.gradient of both,
+ * V (m/s), np.gradient(V)] and targets[T][2] = second np.gradient of the smoothed angles (targets may be null).
+ * Savitzky-Golay as scipy.signal.savgol_filter(x, window, polyorder) with mode='interp' (reference: 11, 3);
+ * T >= window. */
 /* extract_features (simply.py:15-41; main_fun.py:167-193 when with_prev = 0) for T rows:
  * P0, P1 [T][3] in metres, V1 [T][3], time [T], theta [T], gamma [T] ->
  * out[T][18] (or [T][16]) = [P1, V1, A1 = np.gradient(V1, time), unit_rel, tension, angle_proj,
  * theta, gamma (, theta_prev, gamma_prev)]; np.gradient's second-order non-uniform interior
  * stencil and first-order edges. */
+int rovmpc_features_dd(rovmpc_handle *h, const double *P0_mm, const double *P1_mm, const double *V_mm,
+                       const double *time, const double *theta, const double *gamma, int64_t T,
+                       int32_t window, int32_t polyorder, double *features, double *targets);
+
 int rovmpc_extract_features(rovmpc_handle *h, const double *P0, const double *P1, const double *V1,
                             const double *time, const double *theta, const double *gamma,
                             int64_t T, int32_t with_prev, double *out);

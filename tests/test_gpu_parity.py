@@ -411,6 +411,30 @@ def test_generation3_predict_matches_reference_rows(rv, golden_dir):
     assert len(sc["mean"]) == 14
 
 
+def test_features_dd_equal_the_reference(rv, orc, golden_dir):
+    """rovmpc_features_dd vs main_fun.features_dd's own output on the golden log (Savitzky-Golay 11/3 with
+    scipy's edge polynomial, three chained np.gradient passes), then other windows vs the oracle."""
+    d = np.load(os.path.join(golden_dir, "kat_features_dd.npz"))
+    with rv.Engine(rv.MPCConfig(N=2, K=2)) as e:
+        F, Y = e.features_dd(d["P0"], d["P1"], d["V"], d["time"], d["theta"], d["gamma"])
+        np.testing.assert_allclose(F, d["features"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(Y, d["targets"], rtol=1e-8, atol=1e-9)
+        # the shortest admissible log (T = window) and a uniform time base
+        T = 11
+        t = np.arange(T) * 0.05
+        F2, Y2 = e.features_dd(d["P0"][:T], d["P1"][:T], d["V"][:T], t, d["theta"][:T], d["gamma"][:T])
+        Fo, Yo = orc.features_dd(d["P0"][:T], d["P1"][:T], d["V"][:T], t, d["theta"][:T], d["gamma"][:T])
+        np.testing.assert_allclose(F2, Fo, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(Y2, Yo, rtol=1e-8, atol=1e-9)
+        with pytest.raises(ValueError):
+            e.features_dd(d["P0"][:8], d["P1"][:8], d["V"][:8], t[:8], d["theta"][:8], d["gamma"][:8])
+        # other window / order against scipy directly
+        from scipy.signal import savgol_filter
+        F3, _ = e.features_dd(d["P0"], d["P1"], d["V"], d["time"], d["theta"], d["gamma"], window=21, polyorder=5)
+        np.testing.assert_allclose(F3[:, 0], savgol_filter(d["theta"], 21, 5), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(F3[:, 1], savgol_filter(d["gamma"], 21, 5), rtol=1e-9, atol=1e-12)
+
+
 def test_rollout_c3_fp32(rv, orc):
     """BASELINE config 3: N=50, K=16384 in fp32, checked against the fp64 oracle with the rule of
     SURVEY section 8(d): same k*, or |J32 - J64| / J64 < 1e-4 at both minimisers."""
