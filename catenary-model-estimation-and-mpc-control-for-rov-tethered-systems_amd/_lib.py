@@ -79,6 +79,7 @@ _SIGNATURES = {
     "rovmpc_transform_catenary": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, C.c_int32, _P, _P, _P]),
     "rovmpc_velocity_transform": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "rovmpc_extract_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "rovmpc_gaussian_filter1d": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double, _P]),
     "rovmpc_features_dd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "rovmpc_kabsch_velocity_transform": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
 }

@@ -1080,6 +1080,29 @@ extern "C" int rovmpc_features_dd(rovmpc_handle *h, const double *P0_mm, const d
     return ROVMPC_OK;
 }
 
+extern "C" int rovmpc_gaussian_filter1d(rovmpc_handle *h, const double *x, int64_t T, double sigma, double truncate, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (T < 1 || !x || !out || !(sigma > 0) || !(truncate > 0))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_gaussian_filter1d: bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int radius = (int)(truncate * sigma + 0.5);                  // scipy/ndimage/_filters.py gaussian_filter1d
+    if (radius > 4096) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_gaussian_filter1d: kernel radius %d too large", radius);
+    std::vector<double> w(radius + 1);
+    double sum = 0.0;
+    for (int k = -radius; k <= radius; ++k) sum += exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+    for (int k = 0; k <= radius; ++k) w[k] = exp(-0.5 / (sigma * sigma) * (double)k * (double)k) / sum;
+    DevBuf dx, dw, dout;
+    UPLOAD(h, dx, x, (size_t)T * sizeof(double));
+    UPLOAD(h, dw, w.data(), w.size() * sizeof(double));
+    HIPCHK(h, dout.alloc((size_t)T * sizeof(double)));
+    hipLaunchKernelGGL(gaussian_filter1d_kernel, dim3(grid_for(T, 256)), dim3(256), 0, h->stream, dx.as<double>(), (long long)T,
+                       dw.as<double>(), radius, dout.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dout.p, (size_t)T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_kabsch_velocity_transform(rovmpc_handle *h, const double *P, const double *Q, const double *v, int64_t T,
                                                 int32_t M, int32_t batch_gates, double *v_out, double *R_out) {
     if (!h) return ROVMPC_ERR_INVALID;

@@ -292,6 +292,22 @@ features_dd_pass1_kernel(const double *__restrict__ P0mm, const double *__restri
     o[8] = vx; o[9] = vy; o[10] = vz;
 }
 
+// scipy.ndimage.gaussian_filter1d(x, sigma) (mode='reflect', truncate=4): symmetric FIR w[0..radius]
+// (host-normalised), out[i] = w0 x[i] + sum_k w_k (x[i-k] + x[i+k]) with the edge sample repeated.
+__global__ void __launch_bounds__(256)
+gaussian_filter1d_kernel(const double *__restrict__ x, long long T, const double *__restrict__ w, int radius,
+                         double *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    auto at = [&](long long j) {
+        while (j < 0 || j >= T) j = j < 0 ? -j - 1 : 2 * T - j - 1;      // d c b a | a b c d | d c b a
+        return x[j];
+    };
+    double s = w[0] * x[i];
+    for (int k = 1; k <= radius; ++k) s += w[k] * (at(i - k) + at(i + k));
+    out[i] = s;
+}
+
 // passes 2 and 3: np.gradient of `npairs` columns of a [T][ld_src] table into columns of a [T][ld_dst] table.
 __global__ void __launch_bounds__(256)
 gradient_columns_kernel(const double *__restrict__ src, int ld_src, double *__restrict__ dst, int ld_dst,

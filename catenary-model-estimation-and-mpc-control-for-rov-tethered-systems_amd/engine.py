@@ -355,6 +355,12 @@ class Engine:
                                                 T, window, polyorder, _ptr(F), _ptr(Y)))
         return F, Y
 
+    def gaussian_filter1d(self, x, sigma: float, truncate: float = 4.0) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float64).reshape(-1)
+        out = np.empty_like(x)
+        self._check(self.lib.rovmpc_gaussian_filter1d(self._h, _ptr(x), x.shape[0], float(sigma), float(truncate), _ptr(out)))
+        return out
+
     def kabsch_velocity_transform(self, P, Q, v, batch_gates: bool = True):
         P = np.ascontiguousarray(P, np.float64); Q = np.ascontiguousarray(Q, np.float64)
         v = np.ascontiguousarray(v, np.float64).reshape(-1, 3)

@@ -54,3 +54,18 @@ def features_dd(df):
     P1 = df[["robot_cable_attach_point X", "robot_cable_attach_point Y", "robot_cable_attach_point Z"]].values
     V1 = df[["rob_cor_speed X", "rob_cor_speed Y", "rob_cor_speed Z"]].values
     return features_dd_arrays(P0, P1, V1, df["Time"].values, df["Theta"].values, df["Gamma"].values)
+
+
+def preprocess_signals(df, sigma=2):
+    """main_fun.py:768-776: (time, gaussian-smoothed Theta, gaussian-smoothed Gamma).  GPU."""
+    from .engine import default_engine
+    e = default_engine()
+    return df["Time"].values, e.gaussian_filter1d(df["Theta"].values, sigma), e.gaussian_filter1d(df["Gamma"].values, sigma)
+
+
+def compute_derivatives(df):
+    """main_fun.py:645-655: (ddtheta, ddgamma) = second np.gradient of the Savitzky-Golay (11, 3) smoothed angles.  GPU."""
+    T = len(df["Time"].values)
+    z = np.zeros((T, 3))
+    _, Y = features_dd_arrays(z, z + 1.0, z, df["Time"].values, df["Theta"].values, df["Gamma"].values)
+    return Y[:, 0], Y[:, 1]

@@ -290,6 +290,10 @@ int rovmpc_features_dd(rovmpc_handle *h, const double *P0_mm, const double *P1_m
                        const double *time, const double *theta, const double *gamma, int64_t T,
                        int32_t window, int32_t polyorder, double *features, double *targets);
 
+/* scipy.ndimage.gaussian_filter1d(x, sigma, truncate=truncate) with its default 'reflect' boundary
+ * (preprocess_signals, main_fun.py:768-776: sigma 2, truncate 4; build_theta_features_valid :510-518). */
+int rovmpc_gaussian_filter1d(rovmpc_handle *h, const double *x, int64_t T, double sigma, double truncate, double *out);
+
 int rovmpc_extract_features(rovmpc_handle *h, const double *P0, const double *P1, const double *V1,
                             const double *time, const double *theta, const double *gamma,
                             int64_t T, int32_t with_prev, double *out);

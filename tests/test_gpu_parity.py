@@ -435,6 +435,23 @@ def test_features_dd_equal_the_reference(rv, orc, golden_dir):
         np.testing.assert_allclose(F3[:, 1], savgol_filter(d["gamma"], 21, 5), rtol=1e-9, atol=1e-12)
 
 
+def test_smoothing_helpers_equal_the_reference(rv, golden_dir):
+    """preprocess_signals (gaussian_filter1d sigma 2, 'reflect') and compute_derivatives vs main_fun's own outputs."""
+    import pandas as pd
+    d = np.load(os.path.join(golden_dir, "kat_features_dd.npz"))
+    g = np.load(os.path.join(golden_dir, "kat_smoothing.npz"))
+    df = pd.DataFrame({"Time": d["time"], "Theta": d["theta"], "Gamma": d["gamma"]})
+    t, th, ga = rv.preprocess_signals(df, sigma=2)
+    np.testing.assert_allclose(th, g["theta_gauss2"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(ga, g["gamma_gauss2"], rtol=1e-12, atol=1e-15)
+    t, th, ga = rv.preprocess_signals(df.iloc[:6], sigma=3.5)      # kernel radius 14 > 6 rows: repeated reflection
+    np.testing.assert_allclose(th, g["theta_gauss35_first6"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(ga, g["gamma_gauss35_first6"], rtol=1e-12, atol=1e-15)
+    ddt, ddg = rv.compute_derivatives(df)
+    np.testing.assert_allclose(ddt, g["ddtheta"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(ddg, g["ddgamma"], rtol=1e-8, atol=1e-9)
+
+
 def test_rollout_c3_fp32(rv, orc):
     """BASELINE config 3: N=50, K=16384 in fp32, checked against the fp64 oracle with the rule of
     SURVEY section 8(d): same k*, or |J32 - J64| / J64 < 1e-4 at both minimisers."""

@@ -362,6 +362,14 @@ def main():
     np.savez(f"{OUT}/kat_features_dd.npz", time=td, P0=P0d, P1=P1d, V=Vd, theta=dfd["Theta"].values, gamma=dfd["Gamma"].values,
              features=Fd, targets=Yd)
 
+    # 12. smoothing helpers of the analysis scripts on the same log: preprocess_signals (gaussian_filter1d, sigma 2,
+    #     main_fun.py:768-776) and compute_derivatives (savgol 11/3 + two np.gradient passes, main_fun.py:645-655)
+    tt, th_s, ga_s = main_fun.preprocess_signals(dfd, sigma=2)
+    tt3, th_s3, ga_s3 = main_fun.preprocess_signals(dfd.iloc[:6], sigma=3.5)         # log shorter than the kernel radius
+    ddt, ddg = main_fun.compute_derivatives(dfd)
+    np.savez(f"{OUT}/kat_smoothing.npz", theta_gauss2=th_s, gamma_gauss2=ga_s, theta_gauss35_first6=th_s3, gamma_gauss35_first6=ga_s3,
+             ddtheta=ddt, ddgamma=ddg)
+
     print("golden vectors written to", OUT)
 
 
