@@ -76,7 +76,7 @@ template <typename T> struct RolloutArgs {
     long long *slots;             // [world][R] order-preserving int64 image (sharded step) or null
     long long k_offset;
     int rank, world;
-    unsigned long long *stamps;   // diagnostic build only (-DROVMPC_STAMPS): [nblocks][8] 100 MHz ticks
+    unsigned long long *stamps;   // diagnostic build only (-DROVMPC_STAMPS): [nblocks][16] 100 MHz ticks
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -192,13 +192,15 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
 // In-kernel phase stamps exist only in the diagnostic library (make diag, -DROVMPC_STAMPS); the
 // product library contains none of this code.
 #ifdef ROVMPC_STAMPS
-#define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define RV_STAMP_W(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)   // lane 0 of the calling wave
 // slot i <- HW_ID (hwreg 4: wave, simd, pipe, cu, sh, se) | XCC_ID (hwreg 20) << 32: which CU ran the workgroup
-#define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 8 + (i)] = \
+#define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = \
     (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
 #else
 #define RV_STAMP(i) do { } while (0)
 #define RV_STAMP_HW(i) do { } while (0)
+#define RV_STAMP_W(i) do { } while (0)
 #endif
 
 // LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
@@ -222,7 +224,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
     e += (size_t)CK * N;                             // node costs
     if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
-    if (model == MODEL_BUILTIN) e += (size_t)8 * N;                          // candidate-invariant gamma path
+    if (model == MODEL_BUILTIN) e += (size_t)8 * (N + 1);                    // candidate-invariant gamma table
     return e;
 }
 
@@ -253,12 +255,87 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *sU = sA + NA * (N + 1) * CK;                  // [c][n][3]
     T *sC = sU + CK * US;                            // [n][c] node costs
     T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
-    T *sG = sC + CK * N;                             // compiled-in model: gamma-path table [N][8]
-    int *s_prog = s_best_c + 2;                      // gamma-path steps published so far
+    T *sG = sC + CK * N;                             // compiled-in model: gamma table [N + 1][8]
+    int *s_prog = s_best_c + 2;                      // [1]: theta steps finished (early phase-4b batch)
 
     RV_STAMP(0);
+    // state (uniform loads)
+    const double *sd = a.state;
+    const T P0x = (T)sd[0], P0y = (T)sd[1], P0z = (T)sd[2];
+    const T V0x = (T)sd[6], V0y = (T)sd[7], V0z = (T)sd[8];
+    const T A0x = (T)sd[9], A0y = (T)sd[10], A0z = (T)sd[11];
+    const T th0 = (T)sd[12], ga0 = (T)sd[13], thm0 = (T)sd[14], gam0 = (T)sd[15];
+
+    // Compiled-in model: dgamma/dt = x15 - x17 reads gamma and its delay slot only -- no control, no
+    // theta -- so the gamma path is the SAME for every candidate and needs nothing but the state.  One
+    // wave (the "gamma wave") integrates all N steps (gamma_chain) and fills the per-step table the
+    // theta chain and the velocity transform read (gamma_sines) while the other waves are in phase 2a:
+    //   row n: [0] sin gamma_n, [1] cos gamma_n, [2] G_n, [3] sin(x17 at t_n+1), [4] sin(x17 at the
+    //   midpoint), [5] gamma_{n+1};  row N: [0] sin(x17 at t_0).
+    // G_n is the candidate-invariant part of the RK4 sum of dtheta/dt (see theta_path).
+    const int nintB = ((CK + 15) / 16) * 64;                 // theta waves of the compiled-in model
+    const bool wideB = MODEL == MODEL_BUILTIN && NT >= nintB + 64;
+    const bool gwave = MODEL == MODEL_BUILTIN && (wideB ? (tid >= nintB && tid < nintB + 64) : tid < 64);
+    auto gamma_chain = [&]() {
+        const int lane = tid & 63;
+        const int nsteps = (a.debug & 1) ? 0 : N;
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD, euler = a.integrator == ROVMPC_EULER;
+        const T m15 = sMean[15], i15 = sInv[15], m17 = sMean[17], i17 = sInv[17];
+        const T hstep = kk.h, hh = T(0.5) * hstep, h6 = hstep / T(6);
+        // ~20 dependent operations per step in the reference's own order (the recurrence amplifies rounding,
+        // so the affine closed form of the step -- two FMAs -- does not hold 1e-9 beyond ~30 steps: measured),
+        // carried by every lane, stored by lane 0
+        T ga = ga0, gam = gam0;
+        for (int n = 0; n < nsteps; ++n) {
+            const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;          // np.roll delay slot, simply.py:35-38
+            const T p17m = hold ? s17a : (s17a + s17b) / T(2);
+            const T p17e = hold ? s17a : s17b;
+            const T k1g = (ga - m15) * i15 - s17a;
+            T gan;
+            if (euler) {
+                gan = ga + k1g * hstep;                                         // main_fun.py:762
+            } else {
+                const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
+                const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
+                const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
+                gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);          // :66
+            }
+            if (lane == 0) sG[8 * n + 5] = gan;
+            gam = ga; ga = gan;
+        }
+    };
+    auto gamma_sines = [&]() {
+        const int lane = tid & 63;
+        const int nsteps = (a.debug & 1) ? 0 : N;
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD, euler = a.integrator == ROVMPC_EULER;
+        const Trig<T> trig(true);
+        const T m17 = sMean[17], i17 = sInv[17];
+        // item 3n + r -- r = 0 sincos(gamma_n), 1 sin(x17 at t_n+1), 2 sin(x17 at the midpoint); the last
+        // item is sin(x17 at t_0).  One wave's DS operations complete in order, so the reads see the
+        // chain's stores.
+        for (int i = lane; i <= 3 * nsteps; i += 64) {
+            const int n = i == 3 * nsteps ? 0 : i / 3, r = i == 3 * nsteps ? 3 : i - 3 * n;
+            const T g_n = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
+            const T g_m = n == 0 ? gam0 : (n == 1 ? ga0 : sG[8 * (n - 2) + 5]);
+            const T s17a = (g_m - m17) * i17, s17b = (g_n - m17) * i17;
+            T sv, cv;
+            trig.sincos(r == 0 ? g_n : (r == 1 ? s17b : (r == 2 ? (s17a + s17b) / T(2) : s17a)), &sv, &cv);
+            if (r == 0) { sG[8 * n] = sv; sG[8 * n + 1] = cv; }
+            else if (r == 3) sG[8 * N] = sv;
+            else sG[8 * n + 2 + r] = sv;
+        }
+        // G_n = sinA + 4 sinM + sinE (RK4; sinA for Euler), sinA_n = sin(x17 at t_n) = row n-1's [3]
+        for (int n = lane; n < nsteps; n += 64) {
+            const T sinA = n == 0 ? sG[8 * N] : sG[8 * (n - 1) + 3];
+            const T sinM = hold ? sinA : sG[8 * n + 4], sinE = hold ? sinA : sG[8 * n + 3];
+            sG[8 * n + 2] = euler ? sinA : (sinA + sinE) + T(4) * sinM;
+        }
+    };
+
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
-    {
+    // (compiled-in model, wide workgroup: the gamma wave has nothing to fetch)
+    const int ltid = wideB ? (tid < nintB ? tid : tid - 64) : tid, LNT = wideB ? NT - 64 : NT;
+    if (!(wideB && gwave)) {
         const T *src = a.U + (size_t)k0 * N * 3;
         const int tot = nvalid * N * 3;
         constexpr int VW = 16 / sizeof(T);           // elements per 16-byte lane load
@@ -266,7 +343,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         if (vec) {
             typedef T vecT __attribute__((ext_vector_type(VW)));
             const vecT *src4 = reinterpret_cast<const vecT *>(src);
-            for (int i = tid; i < tot / VW; i += NT) {
+            for (int i = ltid; i < tot / VW; i += LNT) {
                 const vecT v = src4[i];
 #pragma unroll
                 for (int e = 0; e < VW; ++e) {
@@ -274,26 +351,19 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     sU[c * US + j] = v[e];
                 }
             }
-            for (int i = tot + tid; i < CK * N * 3; i += NT) {
+            for (int i = tot + ltid; i < CK * N * 3; i += LNT) {
                 const int c = (int)__umulhi((unsigned)i, a.magic_3n), j = i - c * (3 * N);
                 sU[c * US + j] = T(0);
             }
         } else {
-            for (int i = tid; i < CK * N * 3; i += NT) {
+            for (int i = ltid; i < CK * N * 3; i += LNT) {
                 const int c = (int)__umulhi((unsigned)i, a.magic_3n), j = i - c * (3 * N);
                 sU[c * US + j] = (i < tot) ? src[i] : T(0);
             }
         }
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
         if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; }
-
     }
-    // state (uniform loads)
-    const double *sd = a.state;
-    const T P0x = (T)sd[0], P0y = (T)sd[1], P0z = (T)sd[2];
-    const T V0x = (T)sd[6], V0y = (T)sd[7], V0z = (T)sd[8];
-    const T A0x = (T)sd[9], A0y = (T)sd[10], A0z = (T)sd[11];
-    const T th0 = (T)sd[12], ga0 = (T)sd[13], thm0 = (T)sd[14], gam0 = (T)sd[15];
     __syncthreads();
 
     RV_STAMP(1);
@@ -310,7 +380,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
         } else { vx = u[0]; vy = u[1]; vz = u[2]; }
     };
-    for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
+    // (compiled-in model: the gamma wave integrates gamma and fills its table meanwhile)
+    if (gwave) { RV_STAMP_W(8); gamma_chain(); RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10); }
+    for (int i = (wideB && gwave) ? (N + 1) * CK : ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
         // far nodes first: with N*CK threads the one leftover round is then node 0 (no sum at all)
         const int n = N - (i >> cks), c = i & ckm;
         // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
@@ -325,7 +397,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         RV_PL(sP, 0, n, c) = Px; RV_PL(sP, 1, n, c) = Py; RV_PL(sP, 2, n, c) = Pz;
         const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
         {
-            // rotation axes of the cable at this node: used by the velocity transform (phase 3) and
+            // rotation axes of the cable at this node: used by the velocity transform (phases 2b, 3) and
             // again by the augmented-catenary geometry (phase 4b)
             V3<T> kt, kg;
             theta_gamma_axes<T>({rx, ry, rz}, kt, kg);
@@ -407,7 +479,33 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (uses(13)) RV_PL(sX, 13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
         }
     }
+    RV_STAMP(12);
     __syncthreads();
+    RV_STAMP(13);
+    if (MODEL == MODEL_BUILTIN) {
+        // ---- phase 2b: what hangs on gamma_n alone, for every (node, candidate): the gamma plane and the
+        // first half of the velocity transform ------------------------------------------------------------
+        // v_cat = R_theta(+theta_n) R_gamma(-gamma_n) u_n about the cable axes of node n (R @ v of
+        // velocity_transform_batch.py:100-101, R composed from the augmentation angles).  gamma_n is in the
+        // table, so w = R_gamma(-gamma_n) u_n is finished here; of R_theta w the model reads the x component
+        // only, and with kt = (ktx, kty, 0)
+        //   x3 = ((R_theta w).x - mean3) / scale3 = B' + C' cos(theta_n) + A' sin(theta_n),
+        //   A = kty wz,  B = ktx (kt . w),  C = wx - B  (primes: scaled by 1/scale3, B' also shifted).
+        for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
+            const int n = i >> cks, c = i & ckm;
+            RV_PL(sY, 1, n, c) = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
+            if (VT != ROVMPC_VT_COMPOSE || n == N) continue;
+            const T ktx = RV_PL(sA, 0, n, c), kty = RV_PL(sA, 1, n, c);
+            const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+            const T *u = &sU[c * US + n * 3];
+            const V3<T> w = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sG[8 * n], sG[8 * n + 1]);
+            const T B = ktx * (ktx * w.x + kty * w.y);
+            RV_PL(sA, 5, n, c) = (kty * w.z) * sInv[3];
+            RV_PL(sA, 6, n, c) = (B - sMean[3]) * sInv[3];
+            RV_PL(sA, 7, n, c) = (w.x - B) * sInv[3];
+        }
+        __syncthreads();
+    }
 
     RV_STAMP(3);
     // ---- phase 3: closed-loop integration of (theta, gamma), with the state-independent half of
@@ -468,76 +566,23 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
         // saved_models/equations_dgamma_dt.csv complexity 3:  (x15 - x17)
-        // Of the 18 slots only x3, x15, x16, x17 are read.  Two structural facts of these rows
+        // Of the 18 slots only x3, x15, x16, x17 are read.  Three structural facts of these rows
         // shape the phase:
-        //  * dgamma/dt reads gamma and its delay slot only -- no control, no theta.  The gamma
-        //    path is therefore the SAME for every candidate of the step (they share the state):
-        //    one wave (the "gamma wave") integrates it once per workgroup and publishes, per
-        //    horizon step, sincos(gamma_n), the three sines of the x17 slot and gamma_{n+1} in an
-        //    LDS table; the theta waves consume entry n at step n (LDS progress word; LDS is
-        //    coherent within the CU and one wave's DS operations complete in order).
-        //  * every sine argument of a theta step is known once (theta_n, gamma_n) are: each
-        //    candidate owns a quad (lane = 4 c + role); the two closing sines -- sin(x3 at t_n+1),
-        //    sin(x3 at the midpoint) -- are ONE sincos over the wave, exchanged inside the quad with
-        //    DPP quad_perm moves; all four lanes carry the cheap state update redundantly.
-        const int nint = ((CK + 15) / 16) * 64;            // theta waves
+        //  * the gamma path is candidate-invariant and control-free: it was finished beside phase 2a
+        //    (gamma_chain / gamma_sines), and with it everything that hangs on gamma_n alone -- the x17
+        //    sines and the first half of the velocity transform (phase 2b);
+        //  * dtheta/dt does not read the stage state, so the four RK4 slopes of a step are known once
+        //    (theta_n-1, theta_n) and x3 at both ends of the step are.  With x3m = (x3a + x3b) / 2 and
+        //    the interpolated delay slot p16m = (s16a + s16b) / 2 the RK4 sum collapses to
+        //      k1 + 2 k2 + 2 k3 + k4 = KT [ G_n - (sin x3a + 4 sin x3m + sin x3b) - 3 (s16a + s16b) - 3 (x3a + x3b) ],
+        //    G_n = sin x17a + 4 sin x17m + sin x17e from the table (HOLD: 6 s16a; Euler: k1 alone);
+        //  * what is left on the sequential chain per step: x3b = B' + C' cos(theta_n) + A' sin(theta_n), two sines
+        //    (ONE polynomial evaluation over the wave: each candidate owns a quad, lane = 4 c + role,
+        //    roles exchange with DPP quad_perm moves), the sum above, and sincos(theta_n+1) by angle addition.
+        const int nint = nintB;
         const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
         const bool euler = a.integrator == ROVMPC_EULER;
         const int nsteps = (a.debug & 1) ? 0 : N;
-
-        // gamma path, one quad's worth of work: role 1 sincos(gamma_n), role 2 sin(x17 at t_n+1),
-        // role 3 sin(x17 at the midpoint)
-        auto gamma_path = [&]() {
-            const int role = tid & 3;
-            const Trig<T> trig(true);
-            const T m15 = sMean[15], i15 = sInv[15], m17 = sMean[17], i17 = sInv[17];
-            const T hstep = kk.h, hh = T(0.5) * hstep, h6 = hstep / T(6);
-            T ga = ga0, gam = gam0;
-            T s17a = (gam - m17) * i17;
-            T sinA = trig.sin(s17a);
-            for (int n = 0; n < nsteps; ++n) {
-                const T s17b = (ga - m17) * i17;                               // np.roll delay slot, simply.py:35-38
-                const T p17m = hold ? s17a : (s17a + s17b) / T(2);
-                const T p17e = hold ? s17a : s17b;
-                T sv, cv, sr[4], cr4[4];
-                trig.sincos(role == 2 ? s17b : (role == 3 ? p17m : ga), &sv, &cv);
-                quad4(sv, sr); quad4(cv, cr4);
-                const T sinB = sr[2];
-                const T sinM = hold ? sinA : sr[3], sinE = hold ? sinA : sinB;
-                const T k1g = (ga - m15) * i15 - s17a;
-                T gan;
-                if (euler) {
-                    gan = ga + k1g * hstep;                                    // main_fun.py:762
-                } else {
-                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
-                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
-                    const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
-                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);     // :66
-                }
-                if (VT == ROVMPC_VT_COMPOSE) {
-                    // first half of the velocity transform, w = R_gamma(-gamma_n) u_n: it needs gamma_n
-                    // only, so it leaves the theta waves' chain; lane (quad q, role 0) serves candidates
-                    // q, q + 16, ...
-                    if ((tid & 3) == 0) {
-                        for (int cq = (tid & 63) >> 2; cq < CK; cq += 16) {
-                            const V3<T> kg = {RV_PL(sA, 2, n, cq), RV_PL(sA, 3, n, cq), RV_PL(sA, 4, n, cq)};
-                            const T *u = &sU[cq * US + n * 3];
-                            const V3<T> w = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sr[1], cr4[1]);
-                            RV_PL(sA, 5, n, cq) = w.x; RV_PL(sA, 6, n, cq) = w.y; RV_PL(sA, 7, n, cq) = w.z;
-                        }
-                    }
-                }
-                if ((tid & 63) == 0) {
-                    T *g = sG + 8 * n;
-                    g[0] = sr[1]; g[1] = cr4[1]; g[2] = sinA; g[3] = sinM; g[4] = sinE; g[5] = gan;
-                }
-                // every lane's w stores precede this wave's release (DS operations complete in order)
-                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
-                if ((tid & 63) == 0) __hip_atomic_store(s_prog, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                gam = ga; ga = gan; s17a = s17b; sinA = sinB;
-            }
-            if ((tid & 63) == 0) __hip_atomic_store(s_prog, N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
 
         auto theta_path = [&]() {
             const int lane = tid & 63, c16 = lane >> 2, role = lane & 3;
@@ -546,65 +591,46 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const int c = live ? cc : CK - 1;                   // clamp reads of padding lanes
             const Trig<T> trig(true);
             const T m3 = sMean[3], i3 = sInv[3], m16 = sMean[16], i16 = sInv[16];
-            const T hstep = kk.h, h6 = hstep / T(6);            // kk lives in memory: no use inside the loop
             const T KT = T(0.048152514);
+            const T hKT = euler ? kk.h * KT : (kk.h / T(6)) * KT;
             T th = th0, thm = thm0;
-            if (live && role == 0) { RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga0; }
+            if (live && role == 0) RV_PL(sY, 0, 0, c) = th;
             T x3a = (V0x - m3) * i3;
             T sinXa = trig.sin(x3a);
-            // operands of the velocity transform of step 0 (prefetched one step ahead below)
-            T ktx = T(0), kty = T(0), x3n = T(0);
+            // operands of step n, fetched one step ahead (nothing in the loop waits on another wave)
+            T opA = T(0), opB = T(0), opC = T(0), G = T(0);
             auto fetch = [&](int n) {
-                if (VT == ROVMPC_VT_COMPOSE) {
-                    ktx = RV_PL(sA, 0, n, c); kty = RV_PL(sA, 1, n, c);
-                } else {
-                    x3n = RV_PL(sX, 0, n + 1, c);
-                }
+                if (VT == ROVMPC_VT_COMPOSE) { opA = RV_PL(sA, 5, n, c); opB = RV_PL(sA, 6, n, c); opC = RV_PL(sA, 7, n, c); }
+                else opB = RV_PL(sX, 0, n + 1, c);
+                G = sG[8 * n + 2];
             };
             if (nsteps > 0) fetch(0);
             // sincos(theta_n) for the velocity transform.  theta moves by |d| ~ 1e-4 per step, so
             // after a full evaluation at step 0 (and every 16th step, or whenever a lane's |d|
             // reaches 2^-7) the pair is advanced by the angle-addition formulas with the odd/even
-            // Taylor polynomials of d to d^7 / d^8 (truncation < 5e-17): ~14 instructions on the
-            // critical chain instead of ~38.
+            // Taylor polynomials of d to d^7 / d^8 (truncation < 5e-17).
             T st = T(0), ct = T(1);
             if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
             for (int n = 0; n < nsteps; ++n) {
-                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
-                const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
-                while (__hip_atomic_load(s_prog, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= n) __builtin_amdgcn_s_sleep(1);
-                const T *g = sG + 8 * n;
-                const T sinA = g[2], sinM = g[3], sinE = g[4], gan = g[5];
-                T x3b;
-                if (VT == ROVMPC_VT_COMPOSE) {
-                    // velocity_transform: v_cat = R_theta(+theta_n) R_gamma(-gamma_n) v_world with the
-                    // cable axes at node n (R @ v of velocity_transform_batch.py:100-101, R composed
-                    // from the augmentation angles); w = R_gamma(-gamma_n) v_world comes from the gamma
-                    // wave, and only the x component of R_theta w feeds x3
-                    const V3<T> kt = {ktx, kty, T(0)};
-                    const V3<T> w = {RV_PL(sA, 5, n, c), RV_PL(sA, 6, n, c), RV_PL(sA, 7, n, c)};
-                    const V3<T> v = rodrigues_unit<T>(w, kt, st, ct);
-                    x3b = (v.x - m3) * i3;
-                } else {
-                    x3b = x3n;
-                }
+                const T x3b = VT == ROVMPC_VT_COMPOSE ? (opB + opC * ct) + opA * st : opB;
+                const T Gn = G;
                 if (n + 1 < nsteps) fetch(n + 1);
-                const T x3m = (x3a + x3b) / T(2);                             // :62 feature midpoint
+                const T x3s = x3a + x3b;
+                const T x3m = x3s / T(2);                                      // :62 feature midpoint
                 const T s2 = trig.sin((role & 1) ? x3m : x3b);
                 T s2r[4];
                 quad4(s2, s2r);
                 const T sinXb = s2r[0], sinXm = s2r[1];
-                const T k1t = (((sinA - sinXa) - s16a) - x3a) * KT;
-                T thn;
+                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
+                const T s16a = (thm - m16) * i16;
+                T S;
                 if (euler) {
-                    thn = th + k1t * hstep;                                   // main_fun.py:761
+                    S = ((Gn - sinXa) - s16a) - x3a;                           // main_fun.py:761
                 } else {
-                    const T p16m = hold ? s16a : (s16a + s16b) / T(2);
-                    const T p16e = hold ? s16a : s16b;
-                    const T k2t = (((sinM - sinXm) - p16m) - x3m) * KT, k3t = k2t;
-                    const T k4t = (((sinE - sinXb) - p16e) - x3b) * KT;
-                    thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
+                    const T s16 = hold ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
+                    S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
                 }
+                const T thn = th + hKT * S;
                 if (VT == ROVMPC_VT_COMPOSE) {
                     const T dlt = thn - th;
                     const bool big = !(m_abs(dlt) < T(0.0078125));
@@ -621,23 +647,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
                 thm = th; th = thn;
                 x3a = x3b; sinXa = sinXb;
-                if (live && role == 0) { RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = gan; }
-                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = th;
+                // progress word for the early phase-4b batch: one wave's DS operations complete in order,
+                // so the relaxed store cannot pass the theta store above
+                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
 
         // Dispatch (every routine has ONE call site: the kernel is run once through per launch, so
-        // its size is instruction-cache misses).  Wide workgroups: theta waves | one gamma wave |
-        // the rest.  Narrow ones (a single wave): gamma path first, then the theta path.
-        const bool wide = NT >= nint + 64;
-        const bool is_gamma = wide ? (tid >= nint && tid < nint + 64) : (tid < 64);
-        if (is_gamma) {
-            __builtin_amdgcn_s_setprio(2);
-            gamma_path();
-            __builtin_amdgcn_s_setprio(0);
-        }
-        if (!wide) __syncthreads();
+        // its size is instruction-cache misses).  Wide workgroups: theta waves | everybody else on the
+        // state-independent geometry.  Narrow ones (a single wave): the theta path, then the geometry.
+        const bool wide = wideB;
         if (tid < nint) {
             __builtin_amdgcn_s_setprio(3);           // the workgroup's critical path
             theta_path();

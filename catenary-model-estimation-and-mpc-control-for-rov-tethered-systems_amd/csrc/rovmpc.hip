@@ -282,8 +282,8 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_ticket, sizeof(unsigned long long)));
     CR(hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
 #ifdef ROVMPC_STAMPS
-    CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 8 * sizeof(unsigned long long)));
-    CR(hipMemset(h->d_stamps, 0, (size_t)max_blocks * 8 * sizeof(unsigned long long)));
+    CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_stamps, 0, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
 #endif
 #undef CR
     *out = h;
@@ -983,7 +983,7 @@ extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out
     if (!h || !out) return ROVMPC_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
-    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)h->nblocks * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)h->nblocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (nblocks) *nblocks = h->nblocks;
     return ROVMPC_OK;
 }
@@ -1326,6 +1326,9 @@ extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, 
         FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_closed_loop_device: bad argument");
     int rc = check_ready(h);
     if (rc) return rc;
+    if (feedback && h->cfg.feature_map == ROVMPC_FEATURES_GEN3)
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "closed loop with model feedback carries (theta, gamma) only; the second-order map needs the rates "
+                                        "(dtheta, dgamma) in state slots 14/15 -- supply measured rows (feedback = 0)");
     hipStream_t s = (hipStream_t)stream;
     const size_t R = rovmpc_result_len(h);
     const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * h->esz;

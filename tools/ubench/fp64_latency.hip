@@ -4,6 +4,7 @@
 #include <cstdio>
 __global__ void dep_chain(double *out, unsigned long long *cyc, double a, double b, int iters) {
     double x = out[threadIdx.x];
+    unsigned long long w0 = wall_clock64();               // s_memrealtime: constant 100 MHz
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -11,8 +12,9 @@ __global__ void dep_chain(double *out, unsigned long long *cyc, double a, double
     }
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long w1 = wall_clock64();
     out[threadIdx.x] = x;
-    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
 }
 __global__ void indep4(double *out, unsigned long long *cyc, double a, double b, int iters) {
     double x0 = out[threadIdx.x], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
@@ -38,13 +40,17 @@ __global__ void dep_chain_f32(float *out, unsigned long long *cyc, float a, floa
 }
 int main() {
     double *d; unsigned long long *c; float *f;
-    hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&c, 8);
+    hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&c, 16);
     hipMemset(d, 0, 64 * 8); hipMemset(f, 0, 64 * 4);
     unsigned long long h;
     const int iters = 1000;
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL(dep_chain, 1, 64, 0, 0, d, c, 0.999, 0.001, iters); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-        if (rep) printf("fp64 dependent fma : %.2f cycles/op (s_memtime ticks)\n", (double)h / (iters * 16));
+        if (rep) {
+            unsigned long long hw[2]; hipMemcpy(hw, c, 16, hipMemcpyDeviceToHost);
+            printf("fp64 dependent fma : %.2f s_memtime ticks/op = %.2f ns/op (s_memrealtime, 100 MHz); s_memtime runs at %.0f MHz\n",
+                   (double)hw[0] / (iters * 16), 10.0 * hw[1] / (iters * 16), 100.0 * hw[0] / hw[1]);
+        }
         hipLaunchKernelGGL(indep4, 1, 64, 0, 0, d, c, 0.999, 0.001, iters); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
         if (rep) printf("fp64 4 indep chains: %.2f cycles/op\n", (double)h / (iters * 16));
         hipLaunchKernelGGL(dep_chain_f32, 1, 64, 0, 0, f, c, 0.999f, 0.001f, iters); hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
