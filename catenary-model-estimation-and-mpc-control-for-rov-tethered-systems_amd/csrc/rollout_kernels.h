@@ -47,6 +47,8 @@ constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + un
 // Scalars of one handle, resident in device memory and read with scalar loads where they are
 // used.  Passing them by value as kernel arguments kept ~60 SGPRs live across the whole kernel
 // and pushed the sequential phase's loop into SGPR spills (v_writelane/v_readlane per step).
+template <bool B> struct BoolC { static constexpr bool value = B; };   // compile-time flag for generic lambdas
+
 template <typename T> struct RolloutConsts {
     T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up, vs;
     T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
@@ -279,30 +281,35 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     auto gamma_chain = [&]() {
         const int lane = tid & 63;
         const int nsteps = (a.debug & 1) ? 0 : N;
-        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD, euler = a.integrator == ROVMPC_EULER;
         const T m15 = sMean[15], i15 = sInv[15], m17 = sMean[17], i17 = sInv[17];
         const T hstep = kk.h, hh = T(0.5) * hstep, h6 = hstep / T(6);
         // ~20 dependent operations per step in the reference's own order (the recurrence amplifies rounding,
         // so the affine closed form of the step -- two FMAs -- does not hold 1e-9 beyond ~30 steps: measured),
-        // carried by every lane, stored by lane 0
+        // carried by every lane, stored by lane 0.  One loop per mode: no selects on the chain.
         T ga = ga0, gam = gam0;
-        for (int n = 0; n < nsteps; ++n) {
-            const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;          // np.roll delay slot, simply.py:35-38
-            const T p17m = hold ? s17a : (s17a + s17b) / T(2);
-            const T p17e = hold ? s17a : s17b;
-            const T k1g = (ga - m15) * i15 - s17a;
-            T gan;
-            if (euler) {
-                gan = ga + k1g * hstep;                                         // main_fun.py:762
-            } else {
-                const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
-                const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
-                const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
-                gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);          // :66
+        auto run = [&](auto HOLD, auto EULER) {
+            for (int n = 0; n < nsteps; ++n) {
+                const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;      // np.roll delay slot, simply.py:35-38
+                const T p17m = HOLD.value ? s17a : (s17a + s17b) / T(2);
+                const T p17e = HOLD.value ? s17a : s17b;
+                const T k1g = (ga - m15) * i15 - s17a;
+                T gan;
+                if (EULER.value) {
+                    gan = ga + k1g * hstep;                                     // main_fun.py:762
+                } else {
+                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
+                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
+                    const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
+                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);      // :66
+                }
+                if (lane == 0) sG[8 * n + 5] = gan;
+                gam = ga; ga = gan;
             }
-            if (lane == 0) sG[8 * n + 5] = gan;
-            gam = ga; ga = gan;
-        }
+        };
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+        if (a.integrator == ROVMPC_EULER) run(BoolC<false>{}, BoolC<true>{});
+        else if (hold) run(BoolC<true>{}, BoolC<false>{});
+        else run(BoolC<false>{}, BoolC<false>{});
     };
     auto gamma_sines = [&]() {
         const int lane = tid & 63;
