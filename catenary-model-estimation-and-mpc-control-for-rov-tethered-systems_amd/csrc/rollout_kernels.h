@@ -387,11 +387,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
         } else { vx = u[0]; vy = u[1]; vz = u[2]; }
     };
+    const int p2rem = (N + 1) % max(LNT >> cks, 1);    // nodes of the partial last round of phase 2a
     // (compiled-in model: the gamma wave integrates gamma and fills its table meanwhile)
     if (gwave) { RV_STAMP_W(8); gamma_chain(); RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10); }
     for (int i = (wideB && gwave) ? (N + 1) * CK : ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
-        // far nodes first: with N*CK threads the one leftover round is then node 0 (no sum at all)
-        const int n = N - (i >> cks), c = i & ckm;
+        // node order: an item's cost grows with n (an n-term position sum), and the last round is partial.
+        // Full rounds take the far nodes in ascending order (the first waves -- the theta wave among them --
+        // get the cheaper ones), the partial round the nodes next to the anchor, again first waves first.
+        const int q = i >> cks, c = i & ckm;
+        const int n = q < N + 1 - p2rem ? p2rem + q : q - (N + 1 - p2rem);
         // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
         // sequential order by the item itself (independent LDS reads, no scan, no extra barrier)
         T Px = (T)sd[3], Py = (T)sd[4], Pz = (T)sd[5];
