@@ -82,8 +82,10 @@ RV_DEV SinK sin_constants(bool pin) {
     }
     return k;
 }
+constexpr double TRIG_FAST_LIMIT = 67108864.0;     // |x| below this: two-term Cody-Waite reduction is exact enough
+template <bool CHECKED = true>
 RV_DEV double fast_sin_k(double x, const SinK &K) {
-    if (!(::fabs(x) < 67108864.0)) return slow_sincos_f64(x).x;
+    if (CHECKED && !(::fabs(x) < TRIG_FAST_LIMIT)) return slow_sincos_f64(x).x;
     const double k = ::rint(x * K.inv_pi);
     double r = ::fma(-k, K.pi_hi, x);
     r = ::fma(-k, K.pi_lo, r);
@@ -100,12 +102,17 @@ template <> struct Trig<double> {
     TrigK K;
     SinK S;
     RV_DEV explicit Trig(bool pin) : K(trig_constants(pin)), S(sin_constants(pin)) {}
-    RV_DEV double sin(double x) const { return fast_sin_k(x, S); }
+    RV_DEV double sin(double x) const { return fast_sin_k<true>(x, S); }
+    // caller guarantees |x| < TRIG_FAST_LIMIT (and x is not NaN): no large-argument branch on the chain
+    RV_DEV double sin_bounded(double x) const { return fast_sin_k<false>(x, S); }
+    static RV_DEV bool bounded(double b) { return b < TRIG_FAST_LIMIT; }
     RV_DEV void sincos(double x, double *s, double *c) const { fast_sincos_k(x, K, s, c); }
 };
 template <> struct Trig<float> {
     RV_DEV explicit Trig(bool) {}
     RV_DEV float sin(float x) const { return ::sinf(x); }
+    RV_DEV float sin_bounded(float x) const { return ::sinf(x); }
+    static RV_DEV bool bounded(float b) { return b == b; }
     RV_DEV void sincos(float x, float *s, float *c) const { ::sincosf(x, s, c); }
 };
 RV_DEV double m_sin(double x) { double s, c; fast_sincos_f64(x, &s, &c); return s; }

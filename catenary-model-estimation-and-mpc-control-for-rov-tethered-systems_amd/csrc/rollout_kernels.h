@@ -419,7 +419,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (VT != ROVMPC_VT_COMPOSE) {
                 T Vx, Vy, Vz;
                 vel(c, n, Vx, Vy, Vz);
-                RV_PL(sX, 0, n, c) = (Vx - sMean[3]) * sInv[3];              // x3 is all the model reads
+                const T x3 = (Vx - sMean[3]) * sInv[3];                      // x3 is all the model reads
+                RV_PL(sX, 0, n, c) = x3;
+                if (!Trig<T>::bounded(m_abs(x3))) s_prog[0] = 1;             // a sine argument of the theta chain is huge (or NaN)
             }
             continue;
         }
@@ -511,9 +513,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T *u = &sU[c * US + n * 3];
             const V3<T> w = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sG[8 * n], sG[8 * n + 1]);
             const T B = ktx * (ktx * w.x + kty * w.y);
-            RV_PL(sA, 5, n, c) = (kty * w.z) * sInv[3];
-            RV_PL(sA, 6, n, c) = (B - sMean[3]) * sInv[3];
-            RV_PL(sA, 7, n, c) = (w.x - B) * sInv[3];
+            const T Ap = (kty * w.z) * sInv[3], Bp = (B - sMean[3]) * sInv[3], Cp = (w.x - B) * sInv[3];
+            RV_PL(sA, 5, n, c) = Ap; RV_PL(sA, 6, n, c) = Bp; RV_PL(sA, 7, n, c) = Cp;
+            // |x3| <= |A'| + |B'| + |C'| whatever theta is: decides here whether the theta chain may use the
+            // sine without the large-argument branch
+            if (!Trig<T>::bounded((m_abs(Ap) + m_abs(Bp)) + m_abs(Cp))) s_prog[0] = 1;
         }
         __syncthreads();
     }
@@ -616,6 +620,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 G = sG[8 * n + 2];
             };
             if (nsteps > 0) fetch(0);
+            const bool bounded = s_prog[0] == 0 && Trig<T>::bounded(m_abs(x3a));   // every sine argument of the loop is below the fast-path limit
             // sincos(theta_n) for the velocity transform.  theta moves by |d| ~ 1e-4 per step, so
             // after a full evaluation at step 0 (and every 16th step, or whenever a lane's |d|
             // reaches 2^-7) the pair is advanced by the angle-addition formulas with the odd/even
@@ -628,7 +633,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (n + 1 < nsteps) fetch(n + 1);
                 const T x3s = x3a + x3b;
                 const T x3m = x3s / T(2);                                      // :62 feature midpoint
-                const T s2 = trig.sin((role & 1) ? x3m : x3b);
+                const T sarg = (role & 1) ? x3m : x3b;
+                const T s2 = bounded ? trig.sin_bounded(sarg) : trig.sin(sarg);
                 T s2r[4];
                 quad4(s2, s2r);
                 const T sinXb = s2r[0], sinXm = s2r[1];

@@ -530,6 +530,25 @@ def test_threads_per_block_is_validated(rv):
             rv.Engine(rv.MPCConfig(N=4, K=8, threads_per_block=bad))
 
 
+@pytest.mark.parametrize("vt_mode", [0, 1])
+def test_huge_sine_arguments_take_the_checked_path(rv, orc, vt_mode):
+    """One candidate with a control of 3e10 mm/s (|x3| ~ 3e8, beyond the two-term argument reduction): the
+    workgroup that holds it falls back to the checked sine; its neighbours and every other workgroup agree with
+    the oracle as before."""
+    cfg = rv.MPCConfig(N=6, K=48, vt_mode=vt_mode)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, 9)
+    U[5, 2, 0] = 3e10
+    U[37, 0, 0] = -8e9
+    model = rv.default_model()
+    with rv.Engine(cfg, model) as e:
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+        res = e.step(state, U)
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
+    np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(J, Jo, rtol=1e-8)
+    assert res.index == int(np.argmin(Jo))
+
+
 def test_geometry_edge_cases_in_rollout(rv, orc):
     """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
     a vertical cable (degenerate xy projection)."""
