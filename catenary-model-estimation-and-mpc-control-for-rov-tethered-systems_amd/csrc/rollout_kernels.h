@@ -627,48 +627,55 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // Taylor polynomials of d to d^7 / d^8 (truncation < 5e-17).
             T st = T(0), ct = T(1);
             if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
-            for (int n = 0; n < nsteps; ++n) {
-                const T x3b = VT == ROVMPC_VT_COMPOSE ? (opB + opC * ct) + opA * st : opB;
-                const T Gn = G;
-                if (n + 1 < nsteps) fetch(n + 1);
-                const T x3s = x3a + x3b;
-                const T x3m = x3s / T(2);                                      // :62 feature midpoint
-                const T sarg = (role & 1) ? x3m : x3b;
-                const T s2 = bounded ? trig.sin_bounded(sarg) : trig.sin(sarg);
-                T s2r[4];
-                quad4(s2, s2r);
-                const T sinXb = s2r[0], sinXm = s2r[1];
-                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
-                const T s16a = (thm - m16) * i16;
-                T S;
-                if (euler) {
-                    S = ((Gn - sinXa) - s16a) - x3a;                           // main_fun.py:761
-                } else {
-                    const T s16 = hold ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
-                    S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
-                }
-                const T thn = th + hKT * S;
-                if (VT == ROVMPC_VT_COMPOSE) {
-                    const T dlt = thn - th;
-                    const bool big = !(m_abs(dlt) < T(0.0078125));
-                    if (((n + 1) & 15) == 0 || __any(big)) {
-                        trig.sincos(thn, &st, &ct);
+            // One loop for the common mode (RK4, interpolated delay slot, bounded sine arguments) with its flags
+            // as literals, one for everything else with run-time flags.
+            auto run = [&](auto FAST) {
+                const bool eul = FAST.value ? false : euler, hld = FAST.value ? false : hold, bnd = FAST.value ? true : bounded;
+#pragma unroll 2
+                for (int n = 0; n < nsteps; ++n) {
+                    const T x3b = VT == ROVMPC_VT_COMPOSE ? (opB + opC * ct) + opA * st : opB;
+                    const T Gn = G;
+                    if (n + 1 < nsteps) fetch(n + 1);
+                    const T x3s = x3a + x3b;
+                    const T x3m = x3s / T(2);                                  // :62 feature midpoint
+                    const T sarg = (role & 1) ? x3m : x3b;
+                    const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
+                    T s2r[4];
+                    quad4(s2, s2r);
+                    const T sinXb = s2r[0], sinXm = s2r[1];
+                    // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
+                    const T s16a = (thm - m16) * i16;
+                    T S;
+                    if (eul) {
+                        S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
                     } else {
-                        const T d2 = dlt * dlt;
-                        const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
-                        const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
-                        const T sn = st * cd + ct * sd;
-                        ct = ct * cd - st * sd;
-                        st = sn;
+                        const T s16 = hld ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
+                        S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
                     }
+                    const T thn = th + hKT * S;
+                    if (VT == ROVMPC_VT_COMPOSE) {
+                        const T dlt = thn - th;
+                        const bool big = !(m_abs(dlt) < T(0.0078125));
+                        if (((n + 1) & 15) == 0 || __any(big)) {
+                            trig.sincos(thn, &st, &ct);
+                        } else {
+                            const T d2 = dlt * dlt;
+                            const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+                            const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
+                            const T sn = st * cd + ct * sd;
+                            ct = ct * cd - st * sd;
+                            st = sn;
+                        }
+                    }
+                    thm = th; th = thn;
+                    x3a = x3b; sinXa = sinXb;
+                    if (live && role == 0) RV_PL(sY, 0, n + 1, c) = th;
+                    // progress word for the early phase-4b batch: one wave's DS operations complete in order,
+                    // so the relaxed store cannot pass the theta store above
+                    if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                thm = th; th = thn;
-                x3a = x3b; sinXa = sinXb;
-                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = th;
-                // progress word for the early phase-4b batch: one wave's DS operations complete in order,
-                // so the relaxed store cannot pass the theta store above
-                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            };
+            if (!euler && !hold && bounded) run(BoolC<true>{}); else run(BoolC<false>{});
             if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
 
