@@ -8,7 +8,7 @@ import sys
 
 out = {}
 for d in sys.argv[1:]:
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
             if "rollout" in row["Kernel_Name"]:
