@@ -931,12 +931,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         double Jd = __builtin_inf();
         long long kk = 0x7fffffffffffffffLL;
         if (c < nvalid) {
-            // sequential sum (the reference order) with the next term read one step ahead
-            T J = T(0), nxt = sC[c];
-            for (int n = 0; n < N; ++n) {
-                const T cur = nxt;
-                if (n + 1 < N) nxt = sC[(n + 1) * CK + c];
-                J = J + cur;
+            // sequential sum (the reference order).  The terms are fetched ten at a time with clamped addresses
+            // (no branch between the loads), so the LDS latency is paid once per chunk, not once per addition;
+            // terms past the horizon enter as +0.
+            T J = T(0);
+            for (int n0 = 0; n0 < N; n0 += 10) {
+                T v[10];
+#pragma unroll
+                for (int e = 0; e < 10; ++e) v[e] = sC[min(n0 + e, N - 1) * CK + c];
+#pragma unroll
+                for (int e = 0; e < 10; ++e) J = J + (n0 + e < N ? v[e] : T(0));
             }
             if (J != J) J = m_inf<T>();                  // NaN cost never wins the arg-min
             a.J[k0 + c] = J;
@@ -959,7 +963,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             *s_best_c = (int)(kk - k0);
         }
     }
+    RV_STAMP(14);
     __syncthreads();
+    RV_STAMP(15);
     {
         const int cb = *s_best_c;
         double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;

@@ -27,7 +27,7 @@ assert lib.rovmpc_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), C.byr
 st = buf[:nb.value].astype(np.int64)
 t0 = st[:, 0].min()
 names = ["start", "U in LDS", None, "features done", "integration done", "geometry done", "outputs stored", "ticket drawn",
-         "gamma wave: chain starts", "gamma wave: chain done", "gamma wave: sines done", "gamma wave: positions done", "phase 2a done (wave 0)", "phase 2a barrier passed", None, None]
+         "gamma wave: chain starts", "gamma wave: chain done", "gamma wave: sines done", "gamma wave: positions done", "phase 2a done (wave 0)", "phase 2a barrier passed", "phase 5: block arg-min done", "phase 5: barrier passed"]
 print(f"{nb.value} workgroups; times in us from the first workgroup's start (100 MHz clock)")
 for i, n in enumerate(names):
     if n is None:
