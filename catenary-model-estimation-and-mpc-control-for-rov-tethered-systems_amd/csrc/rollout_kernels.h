@@ -152,15 +152,12 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
     const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
     double Jd = __builtin_inf();
     long long kk = 0x7fffffffffffffffLL;
-    for (int b = tid; b < nblocks; b += blockDim.x) {
-        const double oJ = ld_agent(&blk_cost[b]); const long long ok = ld_agent(&blk_idx[b]);
-        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double oJ = __shfl_down(Jd, off, 64);
-        const long long ok = __shfl_down(kk, off, 64);
-        if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; }
-    }
+    auto take = [&](double oJ, long long ok) {
+        const bool better = (oJ < Jd) | ((oJ == Jd) & (ok < kk));
+        Jd = better ? oJ : Jd; kk = better ? ok : kk;
+    };
+    for (int b = tid; b < nblocks; b += blockDim.x) take(ld_agent(&blk_cost[b]), ld_agent(&blk_idx[b]));
+    for (int off = 32; off > 0; off >>= 1) take(__shfl_down(Jd, off, 64), __shfl_down(kk, off, 64));
     if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
     __syncthreads();
     if (tid == 0) {
@@ -948,7 +945,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
         // wave arg-min, lowest index on ties (np.argmin): DPP row shifts when the candidates fit one
         // 16-lane row, ds_bpermute shuffles otherwise
-        auto take = [&](double oJ, long long ok) { if (oJ < Jd || (oJ == Jd && ok < kk)) { Jd = oJ; kk = ok; } };
+        // branch-free: the three compares feed selects (a short-circuit form compiles to exec-mask branches per stage)
+        auto take = [&](double oJ, long long ok) {
+            const bool better = (oJ < Jd) | ((oJ == Jd) & (ok < kk));
+            Jd = better ? oJ : Jd; kk = better ? ok : kk;
+        };
         if (CK <= 16) {
             take(row_shl<8>(Jd), row_shl<8>(kk));
             take(row_shl<4>(Jd), row_shl<4>(kk));
