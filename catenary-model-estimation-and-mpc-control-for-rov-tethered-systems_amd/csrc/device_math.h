@@ -276,7 +276,7 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
             h = sh - r[s] * u[s];
             hp = T(0.5) * (e + ei) - r[s];
         }
-        T un = u[s] - T(2) * h * hp / (T(2) * hp * hp - h * sh);
+        T un = u[s] - (T(2) * h * hp) * fast_rcp(T(2) * hp * hp - h * sh);   // a zero or infinite denominator gives NaN: caught below
         if (!(m_finite(un) && un > T(0))) un = u[s];
         moving[s] = m_abs(un - u[s]) > T(1e-6) * un;
         u[s] = un;
