@@ -651,17 +651,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     }
                     const T thn = th + hKT * S;
                     if (VT == ROVMPC_VT_COMPOSE) {
+                        // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
+                        // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
                         const T dlt = thn - th;
                         const bool big = !(m_abs(dlt) < T(0.0078125));
-                        if (((n + 1) & 15) == 0 || __any(big)) {
-                            trig.sincos(thn, &st, &ct);
-                        } else {
+                        auto advance = [&]() {
                             const T d2 = dlt * dlt;
                             const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
                             const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
                             const T sn = st * cd + ct * sd;
                             ct = ct * cd - st * sd;
                             st = sn;
+                        };
+                        if (((n + 1) & 15) == 0) {
+                            trig.sincos(thn, &st, &ct);
+                        } else if (!__any(big)) {
+                            advance();
+                        } else {                                   // rare: some lane of the wave took a large step
+                            T fs, fc;
+                            trig.sincos(thn, &fs, &fc);
+                            advance();
+                            if (big) { st = fs; ct = fc; }
                         }
                     }
                     thm = th; th = thn;

@@ -549,6 +549,22 @@ def test_huge_sine_arguments_take_the_checked_path(rv, orc, vt_mode):
     assert res.index == int(np.argmin(Jo))
 
 
+def test_a_candidate_does_not_depend_on_its_neighbours(rv):
+    """Bit-for-bit: the same control sequence gives the same cost and trajectory whatever shares its workgroup
+    (NaN, huge or ordinary neighbours change wave-level decisions -- checked sine, re-anchoring -- not results)."""
+    cfg = rv.MPCConfig(N=20, K=64)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=21)
+    U[40] = U[5]; U[50] = U[5]
+    V = U.copy()
+    V[3] = np.nan; V[6, 4, 0] = 5e10; V[41] = 0.0          # neighbours of 5 / 40 / 50 in their workgroups
+    with rv.Engine(cfg) as e:
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+        J2, traj2 = e.rollout_costs(state, V, return_traj=True)
+    assert J[5] == J[40] == J[50] == J2[5] == J2[40] == J2[50]
+    for k in (40, 50):
+        assert np.array_equal(traj[5], traj[k]) and np.array_equal(traj2[5], traj2[k]) and np.array_equal(traj[5], traj2[k])
+
+
 def test_geometry_edge_cases_in_rollout(rv, orc):
     """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
     a vertical cable (degenerate xy projection)."""
