@@ -69,6 +69,7 @@ template <typename T> struct RolloutArgs {
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
+    int NT, nblocks;              // launch geometry (blockDim / gridDim are dependent loads through the implicit arguments)
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
     unsigned magic_3n;            // floor(2^32 / (3N)) + 1: g / (3N) == umulhi(g, magic) for g < 2^16
@@ -145,18 +146,18 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 // doubles of LDS.
 template <typename T>
 RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
-                            const T *U, int N, int CK, double *result, long long k_offset,
+                            const T *U, int N, int CK, int NT, double *result, long long k_offset,
                             long long *slots, int rank, int world, double *scratch) {
     double *sJ = scratch;                                    // [8]
     long long *sK = reinterpret_cast<long long *>(scratch + 8);   // [8]
-    const int tid = threadIdx.x, nw = (blockDim.x + 63) >> 6;
+    const int tid = threadIdx.x, nw = (NT + 63) >> 6;
     double Jd = __builtin_inf();
     long long kk = 0x7fffffffffffffffLL;
     auto take = [&](double oJ, long long ok) {
         const bool better = (oJ < Jd) | ((oJ == Jd) & (ok < kk));
         Jd = better ? oJ : Jd; kk = better ? ok : kk;
     };
-    for (int b = tid; b < nblocks; b += blockDim.x) take(ld_agent(&blk_cost[b]), ld_agent(&blk_idx[b]));
+    for (int b = tid; b < nblocks; b += NT) take(ld_agent(&blk_cost[b]), ld_agent(&blk_idx[b]));
     for (int off = 32; off > 0; off >>= 1) take(__shfl_down(Jd, off, 64), __shfl_down(kk, off, 64));
     if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
     __syncthreads();
@@ -171,7 +172,7 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
-    for (int i = tid; i < R; i += blockDim.x) {
+    for (int i = tid; i < R; i += NT) {
         double v;
         if (i == 0) v = Jbest;
         else if (i == 1) v = (double)(kbest + k_offset);
@@ -181,7 +182,7 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
         if (slots) slots[(size_t)rank * R + i] = ordered_key(v);
     }
     if (slots) {
-        for (int i = tid; i < world * R; i += blockDim.x)
+        for (int i = tid; i < world * R; i += NT)
             if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
     }
 }
@@ -237,7 +238,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
     const RolloutConsts<T> &kk = *a.k;
-    const int tid = threadIdx.x, NT = blockDim.x;
+    const int tid = threadIdx.x, NT = a.NT;
     const int k0 = blockIdx.x * CK;
     const int nvalid = min(CK, K - k0);
     constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
@@ -258,12 +259,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     int *s_prog = s_best_c + 2;                      // [1]: theta steps finished (early phase-4b batch)
 
     RV_STAMP(0);
-    // state (uniform loads)
+    // state: declared here (the gamma lambdas capture it), loaded after the controls' loads are in flight
+    T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
     const double *sd = a.state;
-    const T P0x = (T)sd[0], P0y = (T)sd[1], P0z = (T)sd[2];
-    const T V0x = (T)sd[6], V0y = (T)sd[7], V0z = (T)sd[8];
-    const T A0x = (T)sd[9], A0y = (T)sd[10], A0z = (T)sd[11];
-    const T th0 = (T)sd[12], ga0 = (T)sd[13], thm0 = (T)sd[14], gam0 = (T)sd[15];
 
     // Compiled-in model: dgamma/dt = x15 - x17 reads gamma and its delay slot only -- no control, no
     // theta -- so the gamma path is the SAME for every candidate and needs nothing but the state.  One
@@ -368,6 +366,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
         if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; }
     }
+    // state (uniform loads), behind the controls' loads
+    P0x = (T)sd[0]; P0y = (T)sd[1]; P0z = (T)sd[2];
+    V0x = (T)sd[6]; V0y = (T)sd[7]; V0z = (T)sd[8];
+    A0x = (T)sd[9]; A0y = (T)sd[10]; A0z = (T)sd[11];
+    th0 = (T)sd[12]; ga0 = (T)sd[13]; thm0 = (T)sd[14]; gam0 = (T)sd[15];
     __syncthreads();
 
     RV_STAMP(1);
@@ -1007,7 +1010,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     int *s_last = s_best_c + 1;
     if (tid == 0) {
         const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = ((old + 1ULL) % (unsigned long long)gridDim.x) == 0ULL;
+        *s_last = ((old + 1ULL) % (unsigned long long)a.nblocks) == 0ULL;
     }
     __syncthreads();
     RV_STAMP(7);
@@ -1017,7 +1020,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, (int)gridDim.x, a.U, N, CK, a.result, a.k_offset,
+    argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
                        a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4));
 }
 

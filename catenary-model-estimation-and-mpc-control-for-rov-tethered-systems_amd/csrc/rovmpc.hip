@@ -616,6 +616,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
     a.ticket = h->d_ticket;
+    a.NT = h->NT; a.nblocks = h->nblocks;
     a.stamps = h->d_stamps;
 }
 
