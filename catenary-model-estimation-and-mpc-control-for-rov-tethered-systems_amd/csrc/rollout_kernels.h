@@ -69,6 +69,10 @@ template <typename T> struct RolloutArgs {
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
+    // closed loop: the last workgroup also applies the plant update for the NEXT step (null: no update)
+    const double *plant_next;     // 16 doubles, the measured row of step i + 1
+    double *plant_state;          // the state the next launch reads
+    int plant_feedback;           // 1: keep the model's own (theta, gamma) = first predicted node of this step's winner
     int NT, nblocks;              // launch geometry (blockDim / gridDim are dependent loads through the implicit arguments)
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
@@ -147,7 +151,8 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 template <typename T>
 RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
                             const T *U, int N, int CK, int NT, double *result, long long k_offset,
-                            long long *slots, int rank, int world, double *scratch) {
+                            long long *slots, int rank, int world, double *scratch,
+                            const double *plant_next, double *plant_state, int plant_feedback) {
     double *sJ = scratch;                                    // [8]
     long long *sK = reinterpret_cast<long long *>(scratch + 8);   // [8]
     const int tid = threadIdx.x, nw = (NT + 63) >> 6;
@@ -184,6 +189,19 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
     if (slots) {
         for (int i = tid; i < world * R; i += NT)
             if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
+    }
+    // Closed loop on one GPU: the plant update of the next step (plant_update_kernel's rule) rides on this
+    // workgroup -- every other workgroup has finished, nobody reads the state any more.
+    if (plant_next && tid < 16) {
+        if (!plant_feedback) {
+            plant_state[tid] = plant_next[tid];
+        } else if (tid < 12) {
+            plant_state[tid] = plant_next[tid];
+        } else if (tid == 12) {
+            const double th = plant_state[12], ga = plant_state[13];
+            plant_state[14] = th; plant_state[15] = ga;
+            plant_state[12] = ld_agent(&bt[2]); plant_state[13] = ld_agent(&bt[3]);   // (theta, gamma) of node 1
+        }
     }
 }
 
@@ -1021,7 +1039,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     __syncthreads();
     argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
-                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4));
+                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback);
 }
 
 template <typename T, int MODEL, int VT>

@@ -49,6 +49,9 @@ struct rovmpc_handle {
     long long *d_blk_idx = nullptr;
     unsigned long long *d_ticket = nullptr;
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
+    const double *plant_next = nullptr;       // closed loop: plant update fused into the step being enqueued
+    double *plant_state = nullptr;
+    int plant_feedback = 0;
     double *h_result = nullptr;      // pinned
     // native collective (rovmpc_comm_*)
     ncclComm_t comm = nullptr;
@@ -617,6 +620,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
     a.ticket = h->d_ticket;
     a.NT = h->NT; a.nblocks = h->nblocks;
+    a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
     a.stamps = h->d_stamps;
 }
 
@@ -1333,9 +1337,24 @@ extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, 
     hipStream_t s = (hipStream_t)stream;
     const size_t R = rovmpc_result_len(h);
     const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * h->esz;
+    if (!h->comm) {
+        // one GPU: the plant update of step i + 1 rides on the epilogue of step i (last workgroup), so the
+        // loop is back-to-back rollout kernels; only step 0 needs the stand-alone update
+        hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
+        HIPCHK(h, hipGetLastError());
+        for (int64_t i = 0; i < T; ++i) {
+            const void *U = (const char *)d_pools + (size_t)(i % n_pools) * pool_bytes;
+            h->plant_next = i + 1 < T ? d_exo + (size_t)(i + 1) * 16 : nullptr;
+            h->plant_state = d_state; h->plant_feedback = feedback ? 1 : 0;
+            rc = enqueue_step(h, d_state, U, nullptr, d_results + (size_t)i * R, 0, nullptr, 0, 1, s);
+            h->plant_next = nullptr; h->plant_state = nullptr; h->plant_feedback = 0;
+            if (rc) return rc;
+        }
+        return ROVMPC_OK;
+    }
     for (int64_t i = 0; i < T; ++i) {
         const double *prev = (feedback && i > 0) ? d_results + (size_t)(i - 1) * R : nullptr;
-        if (h->comm && prev) {
+        if (prev) {
             // the previous global record is produced on the side stream
             rc = rovmpc_comm_join(h, s);
             if (rc) return rc;
@@ -1343,8 +1362,7 @@ extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, 
         hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo + (size_t)i * 16, prev);
         HIPCHK(h, hipGetLastError());
         const void *U = (const char *)d_pools + (size_t)(i % n_pools) * pool_bytes;
-        if (h->comm) rc = rovmpc_step_device_allreduce(h, d_state, U, k_offset, d_results + (size_t)i * R, s);
-        else rc = enqueue_step(h, d_state, U, nullptr, d_results + (size_t)i * R, 0, nullptr, 0, 1, s);
+        rc = rovmpc_step_device_allreduce(h, d_state, U, k_offset, d_results + (size_t)i * R, s);
         if (rc) return rc;
     }
     if (h->comm) return rovmpc_comm_join(h, s);
