@@ -69,6 +69,11 @@ template <typename T> struct RolloutArgs {
     long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
+    // sharded step with the library's own collective: GPU-side hand-off of slot row `rank` (null: none).
+    // The row may be written once *flag_consumed >= consumed_need; afterwards *flag_rolled = rolled_seq.
+    const unsigned long long *flag_consumed;
+    unsigned long long *flag_rolled;
+    unsigned long long consumed_need, rolled_seq;
     // closed loop: the last workgroup also applies the plant update for the NEXT step (null: no update)
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
@@ -140,6 +145,8 @@ RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restric
 // to another inside a launch.
 RV_DEV void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV void st_agent(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -152,7 +159,9 @@ template <typename T>
 RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
                             const T *U, int N, int CK, int NT, double *result, long long k_offset,
                             long long *slots, int rank, int world, double *scratch,
-                            const double *plant_next, double *plant_state, int plant_feedback) {
+                            const double *plant_next, double *plant_state, int plant_feedback,
+                            const unsigned long long *flag_consumed, unsigned long long consumed_need,
+                            unsigned long long *flag_rolled, unsigned long long rolled_seq) {
     double *sJ = scratch;                                    // [8]
     long long *sK = reinterpret_cast<long long *>(scratch + 8);   // [8]
     const int tid = threadIdx.x, nw = (NT + 63) >> 6;
@@ -177,6 +186,13 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
+    if (flag_consumed) {
+        // the slot buffer is reused every few steps: its previous contents must have been read by that step's select
+        if (tid == 0) {
+            for (long spin = 0; ld_agent(flag_consumed) < consumed_need && spin < (1L << 26); ++spin) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < R; i += NT) {
         double v;
         if (i == 0) v = Jbest;
@@ -184,11 +200,18 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
         else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
         else v = ld_agent(&bt[i - 5]);
         result[i] = v;
-        if (slots) slots[(size_t)rank * R + i] = ordered_key(v);
+        if (slots) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
     }
     if (slots) {
         for (int i = tid; i < world * R; i += NT)
-            if (i / R != rank) slots[i] = 0x7fffffffffffffffLL;
+            if (i / R != rank) st_agent(&slots[i], 0x7fffffffffffffffLL);
+    }
+    if (flag_rolled) {
+        // publish: the row went out write-through at agent scope; once every wave's stores are acknowledged the
+        // sequence number follows (the collective stream's wait kernel polls it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_agent(flag_rolled, rolled_seq);
     }
     // Closed loop on one GPU: the plant update of the next step (plant_update_kernel's rule) rides on this
     // workgroup -- every other workgroup has finished, nobody reads the state any more.
@@ -1039,7 +1062,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     __syncthreads();
     argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
-                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback);
+                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback,
+                       a.flag_consumed, a.consumed_need, a.flag_rolled, a.rolled_seq);
 }
 
 template <typename T, int MODEL, int VT>
@@ -1051,7 +1075,8 @@ rollout_kernel(const RolloutArgs<T> a) {
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic
 // (cost, global index) minimum and decode it.
 __global__ void __launch_bounds__(64)
-select_kernel(const long long *slots, int world, int R, double *result) {
+select_kernel(const long long *slots, int world, int R, double *result, unsigned long long *flag_consumed = nullptr,
+              unsigned long long consumed_seq = 0) {
     __shared__ int s_r;
     if (threadIdx.x == 0) {
         double Jd = __builtin_inf(); double kd = __builtin_inf(); int rb = 0;
@@ -1065,6 +1090,22 @@ select_kernel(const long long *slots, int world, int R, double *result) {
     __syncthreads();
     const int rb = s_r;
     for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = ordered_val(slots[(size_t)rb * R + i]);
+    if (flag_consumed) {                     // every read of the slot buffer is done: it may be rewritten
+        __syncthreads();
+        if (threadIdx.x == 0) st_agent(flag_consumed, consumed_seq);
+    }
+}
+
+// Collective stream, ahead of the all-reduce of one step: wait until the rollout kernel of that step (running on the
+// caller's stream) has published its row.  One lane polling with agent-scope loads; gives up after ~10 s.
+__global__ void __launch_bounds__(64)
+wait_rolled_kernel(const unsigned long long *flag_rolled, unsigned long long seq, int *timed_out) {
+    if (threadIdx.x != 0) return;
+    for (long spin = 0; spin < (1L << 27); ++spin) {
+        if (ld_agent(flag_rolled) >= seq) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    *timed_out = 1;
 }
 
 // Plant update of the closed-loop driver (one tiny workgroup): exogenous slots from the measured

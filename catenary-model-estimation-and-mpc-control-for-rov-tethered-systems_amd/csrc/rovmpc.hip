@@ -49,6 +49,10 @@ struct rovmpc_handle {
     long long *d_blk_idx = nullptr;
     unsigned long long *d_ticket = nullptr;
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
+    const unsigned long long *arg_flag_consumed = nullptr;   // hand-off flags of the step being enqueued (native collective)
+    unsigned long long *arg_flag_rolled = nullptr;
+    unsigned long long arg_consumed_need = 0, arg_rolled_seq = 0;
+    int *d_wait_timeout = nullptr;
     const double *plant_next = nullptr;       // closed loop: plant update fused into the step being enqueued
     double *plant_state = nullptr;
     int plant_feedback = 0;
@@ -56,14 +60,27 @@ struct rovmpc_handle {
     // native collective (rovmpc_comm_*)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0, comm_flip = 0;
-    hipStream_t comm_stream = nullptr;
     static constexpr int NSLOT = 4;       // collectives in flight (RCCL's small all-reduce is ~2 rollouts long)
+    // Several communicators (each with a high-priority stream of its own), used round-robin by the slots:
+    // collectives on one communicator serialise, and a latency-bound 3 KB all-reduce over 8 GPUs lasts longer than a
+    // rollout -- with more than one communicator the collectives of consecutive steps overlap each other as well as
+    // the rollouts.  Three by default: with the caller's stream that is four hardware queues, the runtime's default
+    // limit (a fifth stream was measured to cost 80 us per step).  comms[0] == comm.
+    static constexpr int NCOMM_MAX = 3;
+    ncclComm_t comms[NCOMM_MAX] = {};
+    hipStream_t comm_streams[NCOMM_MAX] = {};
+    int ncomm = 0;
+    // GPU-side hand-off between the caller's stream and the collective streams (no events on the caller's stream:
+    // an event record costs ~3 us and a cross-stream wait ~6 us of its timeline per step, measured):
+    // rolled[p] = uses of slot p whose rollout has published its row; consumed[p] = uses whose select has read it.
+    unsigned long long *d_flags = nullptr;             // [2][NSLOT]
+    unsigned long long slot_uses[NSLOT] = {};
     long long *d_slots[NSLOT] = {};
     hipEvent_t ev_rolled[NSLOT] = {}, ev_selected[NSLOT] = {};
     bool slot_used[NSLOT] = {};
     // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
     // host time per call) overlaps the enqueue of the next rollout
-    struct CommJob { int p; double *d_result; };
+    struct CommJob { int p; double *d_result; unsigned long long use; };
     std::thread comm_thread;
     std::mutex comm_mu;
     std::condition_variable comm_cv;
@@ -621,6 +638,8 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.ticket = h->d_ticket;
     a.NT = h->NT; a.nblocks = h->nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
+    a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
+    a.consumed_need = h->arg_consumed_need; a.rolled_seq = h->arg_rolled_seq;
     a.stamps = h->d_stamps;
 }
 
@@ -1138,6 +1157,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;   // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -1158,6 +1178,7 @@ static const char *rccl_load() {
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
         return "librccl.so lacks an expected symbol";
     g_rccl = a;
@@ -1194,21 +1215,25 @@ static void comm_worker(rovmpc_handle *h) {
             h->comm_q.pop_front();
         }
         const int p = job.p;
+        ncclComm_t comm = h->comms[p % h->ncomm];
+        hipStream_t cs = h->comm_streams[p % h->ncomm];
+        unsigned long long *f_rolled = h->d_flags + p, *f_consumed = h->d_flags + rovmpc_handle::NSLOT + p;
         std::string err;
-        hipError_t e = hipStreamWaitEvent(h->comm_stream, h->ev_rolled[p], 0);
-        if (e != hipSuccess) err = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e);
+        // the rollout of this use publishes its row with a sequence number; no event on the caller's stream
+        hipLaunchKernelGGL(wait_rolled_kernel, dim3(1), dim3(64), 0, cs, (const unsigned long long *)f_rolled, job.use, h->d_wait_timeout);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) err = std::string("wait kernel: ") + hipGetErrorString(e);
         if (err.empty()) {
-            ncclResult_t r = g_rccl.AllReduce(h->d_slots[p], h->d_slots[p], (size_t)h->comm_world * R, ncclInt64, ncclMin,
-                                              h->comm, h->comm_stream);
+            ncclResult_t r = g_rccl.AllReduce(h->d_slots[p], h->d_slots[p], (size_t)h->comm_world * R, ncclInt64, ncclMin, comm, cs);
             if (r != ncclSuccess) err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
         }
         if (err.empty()) {
-            hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, h->comm_stream, (const long long *)h->d_slots[p],
-                               h->comm_world, (int)R, job.d_result);
+            hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, cs, (const long long *)h->d_slots[p],
+                               h->comm_world, (int)R, job.d_result, f_consumed, job.use);
             e = hipGetLastError();
             if (e != hipSuccess) err = std::string("select kernel: ") + hipGetErrorString(e);
         }
-        e = hipEventRecord(h->ev_selected[p], h->comm_stream);
+        e = hipEventRecord(h->ev_selected[p], cs);
         if (e != hipSuccess && err.empty()) err = std::string("hipEventRecord: ") + hipGetErrorString(e);
         {
             std::lock_guard<std::mutex> lk(h->comm_mu);
@@ -1237,13 +1262,58 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     memcpy(&id, id128, sizeof(id));
     NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
     h->comm_rank = rank; h->comm_world = world; h->comm_flip = 0;
+    h->comms[0] = h->comm; h->ncomm = 1;
+    // high-priority streams: the collective and the select are short and latency-critical, and a
+    // priority stream gets a hardware queue of its own, so they really run beside the rollout
+    // kernels of the caller's stream (two same-priority streams can share a queue)
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->comm_streams[0], hipStreamNonBlocking, hi));
+    HIPCHK(h, hipMalloc((void **)&h->d_flags, 2 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_flags, 0, 2 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
+    HIPCHK(h, hipMalloc((void **)&h->d_wait_timeout, sizeof(int)));
+    HIPCHK(h, hipMemset(h->d_wait_timeout, 0, sizeof(int)));
     {
-        // a high-priority stream: the collective and the select are short and latency-critical,
-        // and a priority stream gets a hardware queue of its own, so they really run beside the
-        // rollout kernels of the caller's stream (two same-priority streams can share a queue)
-        int lo = 0, hi = 0;
-        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+        // More communicators (ROVMPC_COMMS=1 keeps the single one).  Rank 0 draws their ids and hands them round
+        // with ncclBroadcast on the first communicator; every rank then agrees (one all-reduce(min) of a flag) that
+        // all of them came up -- otherwise everybody drops back to the single communicator.
+        int want = rovmpc_handle::NCOMM_MAX;
+        if (const char *e = getenv("ROVMPC_COMMS")) want = atoi(e);
+        if (want > rovmpc_handle::NCOMM_MAX) want = rovmpc_handle::NCOMM_MAX;
+        if (want > 1 && g_rccl.Broadcast) {
+            const int extra = want - 1;
+            ncclUniqueId ids[rovmpc_handle::NCOMM_MAX];
+            memset(ids, 0, sizeof(ids));
+            int ok = 1;
+            if (rank == 0)
+                for (int c = 0; c < extra; ++c)
+                    if (g_rccl.GetUniqueId(&ids[c]) != ncclSuccess) ok = 0;
+            void *d_ids = nullptr; int *d_ok = nullptr;
+            HIPCHK(h, hipMalloc(&d_ids, sizeof(ids)));
+            HIPCHK(h, hipMalloc((void **)&d_ok, sizeof(int)));
+            HIPCHK(h, hipMemcpy(d_ids, ids, sizeof(ids), hipMemcpyHostToDevice));
+            NCCLCHK(h, g_rccl.Broadcast(d_ids, d_ids, sizeof(ids), ncclChar, 0, h->comm, h->comm_streams[0]));
+            HIPCHK(h, hipStreamSynchronize(h->comm_streams[0]));
+            HIPCHK(h, hipMemcpy(ids, d_ids, sizeof(ids), hipMemcpyDeviceToHost));
+            int made = 0;
+            for (int c = 0; c < extra && ok; ++c) {
+                if (g_rccl.CommInitRank(&h->comms[1 + c], world, ids[c], rank) != ncclSuccess) { ok = 0; break; }
+                ++made;
+                if (hipStreamCreateWithPriority(&h->comm_streams[1 + c], hipStreamNonBlocking, hi) != hipSuccess) { ok = 0; break; }
+            }
+            HIPCHK(h, hipMemcpy(d_ok, &ok, sizeof(int), hipMemcpyHostToDevice));
+            NCCLCHK(h, g_rccl.AllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, h->comm, h->comm_streams[0]));
+            HIPCHK(h, hipStreamSynchronize(h->comm_streams[0]));
+            HIPCHK(h, hipMemcpy(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost));
+            (void)hipFree(d_ids); (void)hipFree(d_ok);
+            if (ok) {
+                h->ncomm = want;
+            } else {
+                for (int c = 1; c <= made; ++c) { (void)g_rccl.CommDestroy(h->comms[c]); h->comms[c] = nullptr; }
+                for (int c = 1; c < rovmpc_handle::NCOMM_MAX; ++c)
+                    if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
+            }
+        }
     }
     const size_t R = rovmpc_result_len(h);
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
@@ -1251,6 +1321,7 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_rolled[i], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_selected[i], hipEventDisableTiming));
         h->slot_used[i] = false;
+        h->slot_uses[i] = 0;
         h->comm_submitted[i] = h->comm_done[i] = 0;
     }
     h->comm_stop = false;
@@ -1267,19 +1338,24 @@ extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_st
     hipStream_t s = (hipStream_t)stream;
     const int p = h->comm_flip;
     h->comm_flip = (h->comm_flip + 1) % rovmpc_handle::NSLOT;
-    // slot buffer p is free once the select of NSLOT steps ago has read it
+    // Slot buffer p is free once the select of NSLOT steps ago has read it.  On the host: that job has been handed
+    // to the collective stream (bounds the queue).  On the GPU: the rollout's last workgroup waits for
+    // consumed[p] >= uses - 1 before it writes the row and then publishes rolled[p] = uses; the collective stream
+    // polls that (wait_rolled_kernel).  The caller's stream carries rollout kernels only.
     if (h->slot_used[p]) {
         int rc = comm_wait_enqueued(h, p);
         if (rc) return rc;
-        HIPCHK(h, hipStreamWaitEvent(s, h->ev_selected[p], 0));
     }
     h->slot_used[p] = true;
+    const unsigned long long use = ++h->slot_uses[p];
+    h->arg_flag_consumed = h->d_flags + rovmpc_handle::NSLOT + p; h->arg_consumed_need = use - 1;
+    h->arg_flag_rolled = h->d_flags + p; h->arg_rolled_seq = use;
     int rc = enqueue_step(h, d_state, d_U, nullptr, h->d_result, k_offset, h->d_slots[p], h->comm_rank, h->comm_world, s);
+    h->arg_flag_consumed = nullptr; h->arg_flag_rolled = nullptr;
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev_rolled[p], s));
     {
         std::lock_guard<std::mutex> lk(h->comm_mu);
-        h->comm_q.push_back({p, d_result});
+        h->comm_q.push_back({p, d_result, use});
         ++h->comm_submitted[p];
     }
     h->comm_cv.notify_all();
@@ -1308,17 +1384,21 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     }
     h->comm_cv.notify_all();
     if (h->comm_thread.joinable()) h->comm_thread.join();
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    (void)g_rccl.CommDestroy(h->comm);
-    h->comm = nullptr;
+    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
+        if (h->comm_streams[c]) (void)hipStreamSynchronize(h->comm_streams[c]);
+    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
+        if (h->comms[c]) { (void)g_rccl.CommDestroy(h->comms[c]); h->comms[c] = nullptr; }
+    h->comm = nullptr; h->ncomm = 0;
+    if (h->d_flags) { (void)hipFree(h->d_flags); h->d_flags = nullptr; }
+    if (h->d_wait_timeout) { (void)hipFree(h->d_wait_timeout); h->d_wait_timeout = nullptr; }
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
         if (h->d_slots[i]) (void)hipFree(h->d_slots[i]);
         if (h->ev_rolled[i]) (void)hipEventDestroy(h->ev_rolled[i]);
         if (h->ev_selected[i]) (void)hipEventDestroy(h->ev_selected[i]);
         h->d_slots[i] = nullptr; h->ev_rolled[i] = nullptr; h->ev_selected[i] = nullptr;
     }
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    h->comm_stream = nullptr;
+    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
+        if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
     return ROVMPC_OK;
 }
 

@@ -204,9 +204,12 @@ int rovmpc_select_device(rovmpc_handle *h, const int64_t *d_slots, int32_t world
  * (torch.distributed / MPI / a file), every rank calls rovmpc_comm_init on its handle.
  * rovmpc_step_device_allreduce then enqueues, without synchronising: the fused rollout kernel on
  * `stream`, ONE ncclAllReduce(ncclMin, ncclInt64, world * result_len) and the select kernel on
- * the handle's side stream; d_result is valid once rovmpc_comm_join'ed.  ROVMPC_COMM_SLOTS slot
+ * the handle's side streams; d_result is valid once rovmpc_comm_join'ed.  ROVMPC_COMM_SLOTS slot
  * buffers rotate so the collectives of the last steps overlap the next rollouts; the caller
- * must keep at least that many d_result buffers in rotation. */
+ * must keep at least that many d_result buffers in rotation.  `stream` receives rollout kernels
+ * only: the kernel publishes its row with a sequence number that the side stream polls (no event
+ * record / cross-stream wait on the caller's timeline).  Up to three communicators (environment
+ * ROVMPC_COMMS, default 3) serve the slots in turn so consecutive collectives overlap each other. */
 #define ROVMPC_COMM_SLOTS 4
 int rovmpc_comm_unique_id(void *id128);
 int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t rank, int32_t world);
