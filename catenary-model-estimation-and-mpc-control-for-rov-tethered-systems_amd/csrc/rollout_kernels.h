@@ -189,7 +189,7 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
     if (flag_consumed) {
         // the slot buffer is reused every few steps: its previous contents must have been read by that step's select
         if (tid == 0) {
-            for (long spin = 0; ld_agent(flag_consumed) < consumed_need && spin < (1L << 26); ++spin) __builtin_amdgcn_s_sleep(8);
+            for (long spin = 0; ld_agent(flag_consumed) < consumed_need && spin < (1L << 23); ++spin) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
     }
@@ -1101,7 +1101,7 @@ select_kernel(const long long *slots, int world, int R, double *result, unsigned
 __global__ void __launch_bounds__(64)
 wait_rolled_kernel(const unsigned long long *flag_rolled, unsigned long long seq, int *timed_out) {
     if (threadIdx.x != 0) return;
-    for (long spin = 0; spin < (1L << 27); ++spin) {
+    for (long spin = 0; spin < (1L << 23); ++spin) {
         if (ld_agent(flag_rolled) >= seq) return;
         __builtin_amdgcn_s_sleep(16);
     }

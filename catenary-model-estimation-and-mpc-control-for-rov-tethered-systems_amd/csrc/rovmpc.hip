@@ -1233,8 +1233,7 @@ static void comm_worker(rovmpc_handle *h) {
             e = hipGetLastError();
             if (e != hipSuccess) err = std::string("select kernel: ") + hipGetErrorString(e);
         }
-        e = hipEventRecord(h->ev_selected[p], cs);
-        if (e != hipSuccess && err.empty()) err = std::string("hipEventRecord: ") + hipGetErrorString(e);
+        // (no event per job: rovmpc_comm_join records one per collective stream when somebody needs the results)
         {
             std::lock_guard<std::mutex> lk(h->comm_mu);
             if (!err.empty() && h->comm_err.empty()) h->comm_err = err;
@@ -1365,11 +1364,18 @@ extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_st
 extern "C" int rovmpc_comm_join(rovmpc_handle *h, void *stream) {
     if (!h) return ROVMPC_ERR_INVALID;
     if (!h->comm) return ROVMPC_OK;
+    bool any = false;
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
         if (!h->slot_used[i]) continue;
-        int rc = comm_wait_enqueued(h, i);
+        int rc = comm_wait_enqueued(h, i);          // the worker has handed every job of this slot to its stream
         if (rc) return rc;
-        HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_selected[i], 0));
+        any = true;
+    }
+    if (!any) return ROVMPC_OK;
+    // the worker is idle now, so the collective streams may be touched from this thread: one event per stream
+    for (int c = 0; c < h->ncomm; ++c) {
+        HIPCHK(h, hipEventRecord(h->ev_selected[c], h->comm_streams[c]));
+        HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_selected[c], 0));
     }
     return ROVMPC_OK;
 }
