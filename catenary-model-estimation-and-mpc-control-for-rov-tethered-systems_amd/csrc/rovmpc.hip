@@ -80,7 +80,8 @@ struct rovmpc_handle {
     bool slot_used[NSLOT] = {};
     // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
     // host time per call) overlaps the enqueue of the next rollout
-    struct CommJob { int p; double *d_result; unsigned long long use; };
+    struct CommJob { int p; double *d_result; unsigned long long use; int c; };
+    unsigned long long comm_rr = 0;       // steps issued: communicator of a step = comm_rr % ncomm (same on every rank)
     std::thread comm_thread;
     std::mutex comm_mu;
     std::condition_variable comm_cv;
@@ -1215,8 +1216,8 @@ static void comm_worker(rovmpc_handle *h) {
             h->comm_q.pop_front();
         }
         const int p = job.p;
-        ncclComm_t comm = h->comms[p % h->ncomm];
-        hipStream_t cs = h->comm_streams[p % h->ncomm];
+        ncclComm_t comm = h->comms[job.c];
+        hipStream_t cs = h->comm_streams[job.c];
         unsigned long long *f_rolled = h->d_flags + p, *f_consumed = h->d_flags + rovmpc_handle::NSLOT + p;
         std::string err;
         // the rollout of this use publishes its row with a sequence number; no event on the caller's stream
@@ -1260,7 +1261,7 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
-    h->comm_rank = rank; h->comm_world = world; h->comm_flip = 0;
+    h->comm_rank = rank; h->comm_world = world; h->comm_flip = 0; h->comm_rr = 0;
     h->comms[0] = h->comm; h->ncomm = 1;
     // high-priority streams: the collective and the select are short and latency-critical, and a
     // priority stream gets a hardware queue of its own, so they really run beside the rollout
@@ -1354,7 +1355,7 @@ extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_st
     if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(h->comm_mu);
-        h->comm_q.push_back({p, d_result, use});
+        h->comm_q.push_back({p, d_result, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm)});
         ++h->comm_submitted[p];
     }
     h->comm_cv.notify_all();
