@@ -565,6 +565,17 @@ def test_a_candidate_does_not_depend_on_its_neighbours(rv):
         assert np.array_equal(traj[5], traj[k]) and np.array_equal(traj2[5], traj2[k]) and np.array_equal(traj[5], traj2[k])
 
 
+@pytest.mark.parametrize("N,K,dt,vt", [(150, 40, 1 / 240, 1), (100, 33, 1 / 240, 0), (21, 1, 1 / 60, 1), (23, 4097, 1 / 60, 1)])
+def test_long_horizons_and_odd_sizes(rv, orc, N, K, dt, vt):
+    """Horizons beyond one round of the table passes (3N + 2 > 64 items on the gamma wave), small workgroups forced
+    by the LDS budget, a single candidate, one candidate past a multiple of the workgroup size."""
+    cfg = rv.MPCConfig(N=N, K=K, dt=dt, vt_mode=vt)
+    (J, traj, res), (Jo, trajo, aux), _ = run_both(rv, orc, cfg, seed=N)
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    assert res.index == int(np.argmin(Jo))
+
+
 def test_geometry_edge_cases_in_rollout(rv, orc):
     """Taut cable, root above the bracket (tension fallback + straight-segment shape), NED frame,
     a vertical cable (degenerate xy projection)."""
