@@ -207,6 +207,8 @@ def main():
 
     if rank == 0:
         units_per_step = world * args.K * args.N
+        tag = ("C2" if (args.N, args.K, args.dtype) == (20, 4096, "f64") else
+               "C3" if (args.N, args.K, args.dtype) == (50, 16384, "f32") else "other size")     # BASELINE.json configs
         esz = 8 if args.dtype == "f64" else 4
         alg_bytes = args.K * args.N * 3 * esz + args.K * esz          # controls in, costs out
         out = {
@@ -217,7 +219,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C2: one MPC step, N={args.N} horizon x K={args.K} candidates per GPU "
+            "config": {"workload": f"{tag}: one MPC step, N={args.N} horizon x K={args.K} candidates per GPU "
                                    f"(global K={world * args.K}), fused RK4+catenary HIP kernel, {args.dtype}",
                        "N": args.N, "K_per_gpu": args.K, "K_global": world * args.K,
                        "n_shape_pts": cfg.n_shape_pts, "vt_mode": "compose", "dt": cfg.dt,
