@@ -977,6 +977,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 
     RV_STAMP(5);
     // ---- phase 5: J_k, block arg-min, outputs ---------------------------------------------
+    const bool fast_tail = a.result && !a.traj_all && N + 1 <= 64;
     if (tid < 64) {
         const int c = tid;
         double Jd = __builtin_inf();
@@ -1017,11 +1018,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             st_agent(&a.blk_idx[blockIdx.x], kk);
             *s_best_c = (int)(kk - k0);
         }
+        if (fast_tail) {
+            // the common case: this wave alone hands the workgroup's best over (lane 0 holds it after the reduction) --
+            // trajectory stores, drain, ticket -- and the other waves meet it at ONE barrier to learn whether the
+            // workgroup is the last to arrive
+            const int cb = __builtin_amdgcn_readfirstlane((int)(kk - k0));
+            double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
+            if (c <= N) {
+                st_agent(&bt[2 * c], (double)RV_PL(sY, 0, c, cb));
+                st_agent(&bt[2 * c + 1], (double)RV_PL(sY, 1, c, cb));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c == 0) {
+                const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_best_c[1] = ((old + 1ULL) % (unsigned long long)a.nblocks) == 0ULL;
+            }
+        }
     }
     RV_STAMP(14);
     __syncthreads();
     RV_STAMP(15);
-    {
+    if (!fast_tail) {
         const int cb = *s_best_c;
         double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
         for (int i = tid; i < (N + 1); i += NT) {
@@ -1038,6 +1055,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     RV_STAMP(6);
     if (!a.result) return;
+    int *s_last = s_best_c + 1;
+    if (!fast_tail) {
 
     // ---- arg-min epilogue in the last workgroup to arrive ------------------------------------
     // Hand-off (cdna_hip_programming.md G16, counter form): every handed-off byte is stored
@@ -1048,12 +1067,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // launch of this handle adds exactly gridDim.x.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int *s_last = s_best_c + 1;
     if (tid == 0) {
         const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_last = ((old + 1ULL) % (unsigned long long)a.nblocks) == 0ULL;
     }
     __syncthreads();
+    }
     RV_STAMP(7);
     if (!*s_last) return;
     if (tid == 0) {
