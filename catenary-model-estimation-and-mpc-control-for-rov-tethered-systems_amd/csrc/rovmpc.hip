@@ -76,7 +76,7 @@ struct rovmpc_handle {
     unsigned long long *d_flags = nullptr;             // [2][NSLOT]
     unsigned long long slot_uses[NSLOT] = {};
     long long *d_slots[NSLOT] = {};
-    hipEvent_t ev_rolled[NSLOT] = {}, ev_selected[NSLOT] = {};
+    hipEvent_t ev_selected[NSLOT] = {};   // recorded at rovmpc_comm_join, one per collective stream
     bool slot_used[NSLOT] = {};
     // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
     // host time per call) overlaps the enqueue of the next rollout
@@ -1318,7 +1318,6 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     const size_t R = rovmpc_result_len(h);
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
         HIPCHK(h, hipMalloc((void **)&h->d_slots[i], (size_t)world * R * sizeof(long long)));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_rolled[i], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->ev_selected[i], hipEventDisableTiming));
         h->slot_used[i] = false;
         h->slot_uses[i] = 0;
@@ -1400,9 +1399,8 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     if (h->d_wait_timeout) { (void)hipFree(h->d_wait_timeout); h->d_wait_timeout = nullptr; }
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
         if (h->d_slots[i]) (void)hipFree(h->d_slots[i]);
-        if (h->ev_rolled[i]) (void)hipEventDestroy(h->ev_rolled[i]);
         if (h->ev_selected[i]) (void)hipEventDestroy(h->ev_selected[i]);
-        h->d_slots[i] = nullptr; h->ev_rolled[i] = nullptr; h->ev_selected[i] = nullptr;
+        h->d_slots[i] = nullptr; h->ev_selected[i] = nullptr;
     }
     for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
         if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
