@@ -15,6 +15,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import _lib
 from .engine import Engine
 from .trajgen import generate_rov_trajectories
 
@@ -43,11 +44,30 @@ def closed_loop_inputs(engine: Engine, exp_case: int, n_steps: int, seed: int = 
     V = np.gradient(P1, cfg.dt, axis=0) / cfg.v_scale          # m/s -> rob_cor_speed units
     A = np.gradient(V, cfg.dt, axis=0)
     mean, scale = engine.model.mean, engine.model.scale
-    th = mean[14] + scale[14] * np.sin(2 * np.pi * t / 7.0)
-    ga = mean[15] + scale[15] * np.cos(2 * np.pi * t / 11.0)
-    thp = np.roll(th, 1); gap = np.roll(ga, 1); thp[0] = th[0]; gap[0] = ga[0]
+    it, ig = angle_slots(cfg.feature_map)
+    th = mean[it] + scale[it] * np.sin(2 * np.pi * t / 7.0)
+    ga = mean[ig] + scale[ig] * np.cos(2 * np.pi * t / 11.0)
+    if cfg.feature_map == _lib.FEATURES_GEN3:          # second-order map: slots 14/15 of the state carry the rates
+        thp = np.gradient(th, cfg.dt); gap = np.gradient(ga, cfg.dt)
+    else:
+        thp = np.roll(th, 1); gap = np.roll(ga, 1); thp[0] = th[0]; gap[0] = ga[0]
     rows = np.ascontiguousarray(np.hstack([P0, P1, V, A, th[:, None], ga[:, None], thp[:, None], gap[:, None]])[:n_steps])
     return rows, rows[0].copy()
+
+
+def angle_slots(feature_map: int):
+    """(theta slot, gamma slot) of the scaler for a feature map."""
+    return {_lib.FEATURES_GEN1: (14, 15), _lib.FEATURES_GEN2: (12, 13), _lib.FEATURES_GEN3: (0, 1)}[feature_map]
+
+
+def velocity_prior(engine: Engine):
+    """(mean(3), scale(3)) of the candidate controls in rob_cor_speed units, from the scaler's velocity slots."""
+    m, s = engine.model.mean, engine.model.scale
+    if engine.cfg.feature_map == _lib.FEATURES_GEN3:   # V_x..V_z are slots 8..10, in m/s
+        return m[8:11] / engine.cfg.v_scale, s[8:11] / engine.cfg.v_scale
+    if engine.cfg.feature_map == _lib.FEATURES_GEN2:   # unscaled model: the generation-1 spread
+        return np.array([80.85, -20.13, -18.35]), np.array([108.49, 15.88, 63.13])
+    return m[3:6], s[3:6]
 
 
 def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_pools: int = 8,
@@ -60,7 +80,8 @@ def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_p
     dev = torch.device("cuda", cfg.device)
     tdt = torch.float64 if cfg.dtype == "f64" else torch.float32
     exo_np, state_np = closed_loop_inputs(engine, exp_case, n_steps, seed)
-    mean = torch.tensor(engine.model.mean[3:6], device=dev); scale = torch.tensor(engine.model.scale[3:6], device=dev)
+    vm, vs = velocity_prior(engine)
+    mean = torch.tensor(np.ascontiguousarray(vm), device=dev); scale = torch.tensor(np.ascontiguousarray(vs), device=dev)
     g = torch.Generator(device=dev); g.manual_seed(seed + 1000 * k_offset)
     pools = (mean + scale * torch.randn((n_pools, cfg.K, cfg.N, 3), generator=g, device=dev, dtype=torch.float64)).to(tdt).contiguous()
     exo = torch.tensor(exo_np, device=dev)

@@ -761,6 +761,27 @@ def test_mpc_step_surface_and_closed_loop(rv):
     mpc.close()
 
 
+def test_closed_loop_second_order_model(rv):
+    """Device-side closed loop with the second-order generation (measured rows carry the rates): equals stepping by
+    hand; model feedback is refused (it would need the rates of the winner)."""
+    import torch
+    from rovmpc.closed_loop import run_closed_loop, closed_loop_inputs, velocity_prior
+    eng = rv.Engine(rv.MPCConfig(N=10, K=256, feature_map=rv.FEATURES_GEN3), rv.generation3_model())
+    rep = run_closed_loop(eng, exp_case=12, n_steps=12)
+    assert np.isfinite(rep.cost).all()
+    rows, _ = closed_loop_inputs(eng, 12, 12)
+    vm, vs = velocity_prior(eng)
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    pools = (torch.tensor(vm, device="cuda") + torch.tensor(vs, device="cuda")
+             * torch.randn((8, 256, 10, 3), generator=g, device="cuda", dtype=torch.float64)).cpu().numpy()
+    for i in range(4):
+        r = eng.step(rows[i], pools[i % 8])
+        assert r.cost == rep.cost[i] and np.array_equal(r.u, rep.u[i])
+    with pytest.raises(rv.RovmpcError):
+        run_closed_loop(eng, exp_case=12, n_steps=4, feedback=True)
+    eng.close()
+
+
 def test_error_behaviour(rv):
     with pytest.raises(rv.RovmpcError):
         rv.Engine(rv.MPCConfig(N=0, K=4))
