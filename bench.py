@@ -251,6 +251,14 @@ def main():
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 out["roofline"]["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
                 out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+            if "SQ_WAVE_CYCLES" in pmc and "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
+                # what actually bounds the kernel (same committed PMC passes): share of the waves' lifetime spent
+                # waiting (barriers, dependent latencies) vs issuing VALU
+                wc = pmc["SQ_WAVE_CYCLES"]["mean"]
+                out["roofline"]["wave_cycles_waiting_frac"] = pmc["SQ_WAIT_ANY"]["mean"] / wc
+                out["roofline"]["wave_cycles_valu_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc
+                if "SQ_INSTS_VALU" in pmc:
+                    out["roofline"]["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]["mean"]
         if world == 1 and smpc is None and S == 1 and not args.no_pipelined_extra:
             # extra, not the headline: two independent MPC steps in flight on one GPU (second engine handle
             # on a high-priority stream = its own hardware queue), so one step's launch ramp / arg-min tail
