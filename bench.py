@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipelined-extra", action="store_true")
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
-    ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows)")
+    ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows) | gen2 | gen3")
     ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
     args = ap.parse_args()
 
@@ -112,6 +112,12 @@ def main():
     model = rovmpc.default_model()
     if args.model == "jit-default":
         model = rovmpc.DynamicsModel(model.mean, model.scale, model.expr_theta + " + 0.0*x0", model.expr_gamma)
+    elif args.model == "gen3":          # second-order generation on the features_dd map (dd_cluster.py)
+        model = rovmpc.generation3_model()
+        cfg.feature_map = rovmpc.FEATURES_GEN3
+    elif args.model == "gen2":          # 17 unscaled features (simulate_rk4_theta_gamma.py)
+        model = rovmpc.generation2_model()
+        cfg.feature_map = rovmpc.FEATURES_GEN2
     elif args.model.startswith("rows:"):
         ct, cg = (int(v) for v in args.model[5:].split(","))
         model = rovmpc.default_model(ct, cg)
