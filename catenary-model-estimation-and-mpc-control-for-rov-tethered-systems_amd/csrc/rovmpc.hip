@@ -1395,6 +1395,8 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
         if (h->comms[c]) { (void)g_rccl.CommDestroy(h->comms[c]); h->comms[c] = nullptr; }
     h->comm = nullptr; h->ncomm = 0;
+    int timed_out = 0;
+    if (h->d_wait_timeout) (void)hipMemcpy(&timed_out, h->d_wait_timeout, sizeof(int), hipMemcpyDeviceToHost);
     if (h->d_flags) { (void)hipFree(h->d_flags); h->d_flags = nullptr; }
     if (h->d_wait_timeout) { (void)hipFree(h->d_wait_timeout); h->d_wait_timeout = nullptr; }
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
@@ -1404,6 +1406,8 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     }
     for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
         if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
+    if (timed_out)
+        FAIL(h, ROVMPC_ERR_HIP, "a collective gave up waiting for its rollout kernel (~10 s): results of that step are not valid");
     return ROVMPC_OK;
 }
 
