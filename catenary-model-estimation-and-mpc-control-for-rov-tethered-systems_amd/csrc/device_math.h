@@ -242,8 +242,14 @@ template <typename T> struct CatRoot { T C, u, r; };
 // NS independent systems advance in lockstep: the per-node rollout needs two solves (cable
 // tension on the straight geometry, shape on the theta-rotated end point) and interleaving
 // them doubles the instruction-level parallelism of an otherwise latency-bound chain.
+// Warm start (u_warm, ch_warm = cosh u_warm): the root of a NEARBY system -- the rollout solves the same cable at
+// the same node twice, for the end point and for the end point turned by theta about a horizontal axis, a few
+// parts in a thousand apart -- accepted when h'(u_warm) = cosh u_warm - r > 0 (Newton-type steps from there land
+// above the root and descend).  Two iterations then reach 1e-14 (measured over the benchmark's geometry); a system
+// without a usable warm start takes the series bound and the tail loop runs the extra iterations it needs.
 template <typename T, int NS>
-RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_lo, T c_hi, CatRoot<T> (&out)[NS]) {
+RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_lo, T c_hi, CatRoot<T> (&out)[NS],
+                                 const T *u_warm = nullptr, const T *ch_warm = nullptr) {
     T u[NS], r[NS], rm1[NS];
     bool ok[NS], moving[NS];          // moving: the last step changed u by more than 1e-6 relative
 #pragma unroll
@@ -252,13 +258,19 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
         const T sq = m_sqrt(L2);
         r[s] = sq / l[s];
         rm1[s] = (L2 - l[s] * l[s]) / (l[s] * (sq + l[s]));
-        u[s] = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1[s] * T(1.0 / 30.0))), T(0)));
-        ok[s] = rm1[s] > T(0) && m_finite(r[s]) && m_finite(u[s]) && u[s] > T(0);
-        if (!ok[s]) { u[s] = T(1); r[s] = T(2); rm1[s] = T(1); }
-        if (r[s] > T(8)) {
-            T ul = m_log(T(2) * r[s] * u[s]);
-            ul = m_log(T(2) * r[s] * ul) + T(0.05);
-            if (ul > T(0) && ul < u[s]) u[s] = ul;
+        const bool warm = u_warm && u_warm[s] > T(0) && ch_warm[s] > r[s] && rm1[s] > T(0) && m_finite(r[s]);
+        if (warm) {
+            u[s] = u_warm[s];
+            ok[s] = true;
+        } else {
+            u[s] = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1[s] * T(1.0 / 30.0))), T(0)));
+            ok[s] = rm1[s] > T(0) && m_finite(r[s]) && m_finite(u[s]) && u[s] > T(0);
+            if (!ok[s]) { u[s] = T(1); r[s] = T(2); rm1[s] = T(1); }
+            if (r[s] > T(8)) {
+                T ul = m_log(T(2) * r[s] * u[s]);
+                ul = m_log(T(2) * r[s] * ul) + T(0.05);
+                if (ul > T(0) && ul < u[s]) u[s] = ul;
+            }
         }
         moving[s] = true;
     }
@@ -281,10 +293,13 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
         moving[s] = m_abs(un - u[s]) > T(1e-6) * un;
         u[s] = un;
     };
+    const int fixed = u_warm ? 2 : 3;
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
+        if (it < fixed) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) halley(s);
+            for (int s = 0; s < NS; ++s) halley(s);
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -302,6 +317,12 @@ template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_
     const T la[1] = {l}, da[1] = {dH};
     CatRoot<T> o[1];
     solve_catenary_roots<T, 1>(la, da, L, c_lo, c_hi, o);
+    return o[0];
+}
+template <typename T> RV_DEV CatRoot<T> solve_catenary_root_warm(T l, T dH, T L, T c_lo, T c_hi, T u_warm, T ch_warm) {
+    const T la[1] = {l}, da[1] = {dH}, uw[1] = {u_warm}, cw[1] = {ch_warm};
+    CatRoot<T> o[1];
+    solve_catenary_roots<T, 1>(la, da, L, c_lo, c_hi, o, uw, cw);
     return o[0];
 }
 

@@ -264,6 +264,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     e += planes * (size_t)(N + 1) * CK;              // node planes
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
     e += (size_t)CK * N;                             // node costs
+    e += (size_t)2 * CK * N;                         // warm start of the second catenary solve of a node (u, cosh u)
     if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
     if (model == MODEL_BUILTIN) e += (size_t)8 * (N + 1);                    // candidate-invariant gamma table
     return e;
@@ -295,8 +296,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *sA = sX + NX * (N + 1) * CK;                  // NA planes (rotation axes [, unit_rel])
     T *sU = sA + NA * (N + 1) * CK;                  // [c][n][3]
     T *sC = sU + CK * US;                            // [n][c] node costs
-    T *sF = sC + CK * N;                             // interpreter: 18 feature rows + stack
-    T *sG = sC + CK * N;                             // compiled-in model: gamma table [N + 1][8]
+    T *sW = sC + CK * N;                             // [2][n][c]: root of phase 4a's solve and its cosh (warm start of 4b's)
+    T *sF = sW + 2 * CK * N;                         // interpreter: 18 feature rows + stack
+    T *sG = sW + 2 * CK * N;                             // compiled-in model: gamma table [N + 1][8]
     int *s_prog = s_best_c + 2;                      // [1]: theta steps finished (early phase-4b batch)
 
     RV_STAMP(0);
@@ -584,6 +586,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
             const CatRoot<T> cr = solve_catenary_root<T>(l, dH, kk.L, kk.c_lo, kk.c_hi);   // :303
             const T Tn = cable_tension<T>(l, cr, kk.w_per_len);                   // :304-305
+            {
+                const T shu = cr.r * cr.u;                                        // sinh u at the root
+                sW[n * CK + c] = (cr.C == cr.C) ? cr.u : T(-1);
+                sW[(N + n) * CK + c] = m_sqrt(T(1) + shu * shu);
+            }
             const T e0 = u[0] - kk.Uref[0], e1 = u[1] - kk.Uref[1], e2 = u[2] - kk.Uref[2];
             const T taut = m_max(T(0), d - kk.rhoL);
             sC[n * CK + c] = kk.w_u * (e0 * e0 + e1 * e1 + e2 * e2) + kk.w_T * Tn + kk.w_taut * (taut * taut);
@@ -602,7 +609,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const V3<T> kt = {RV_PL(sA, 0, n + 1, c), RV_PL(sA, 1, n + 1, c), T(0)};
         const V3<T> kg = {RV_PL(sA, 2, n + 1, c), RV_PL(sA, 3, n + 1, c), RV_PL(sA, 4, n + 1, c)};
         const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, kt, kg, th, ga, kk.up, trig4);
-        const CatRoot<T> cr = solve_catenary_root<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi);   // Catenary(A, B')
+        const CatRoot<T> cr = solve_catenary_root_warm<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi, sW[n * CK + c], sW[(N + n) * CK + c]);   // Catenary(A, B')
         const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
         const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
         const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
