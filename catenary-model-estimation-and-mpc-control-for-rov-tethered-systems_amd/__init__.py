@@ -19,6 +19,6 @@ from .integrate import (SymbolicRegressor, rk4_integration, integrate_theta_gamm
                         integrate_second_order)
 from .features import extract_features, extract_features_arrays, extract_features_host, features_dd, features_dd_arrays, preprocess_signals, compute_derivatives
 from .trajgen import generate_rov_trajectories, trajectory_csv
-from .mpc import MPC, GaussianSampler, synthetic_problem
+from .mpc import MPC, GaussianSampler, DeviceGaussianSampler, synthetic_problem
 
 __version__ = "0.1.0"

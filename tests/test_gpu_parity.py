@@ -782,6 +782,39 @@ def test_closed_loop_second_order_model(rv):
     eng.close()
 
 
+def test_mpc_step_with_device_side_sampling(rv, orc):
+    """MPC(device_sampling=True): candidates drawn on the GPU; the returned control is the arg-min of exactly those
+    candidates (checked against the oracle on a copy of the device tensor), warm start pins candidate 0."""
+    import time
+    mpc = rv.MPC(N=12, K=256, device_sampling=True)
+    state, _ = rv.synthetic_problem(256, 12)
+    u = mpc.step(state)
+    U = mpc._dev["sampler"].U.cpu().numpy()
+    model = rv.default_model()
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, mpc.cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
+    k = int(np.argmin(Jo))
+    assert mpc.last.index == k and np.array_equal(u, U[k, 0])
+    assert mpc.last.cost == pytest.approx(Jo[k], rel=RTOL)
+    np.testing.assert_allclose(mpc.last.traj, trajo[k], rtol=RTOL, atol=1e-13)
+    best = U[k].copy()
+    u2 = mpc.step(state)
+    U2 = mpc._dev["sampler"].U.cpu().numpy()
+    np.testing.assert_array_equal(U2[0], np.vstack([best[1:], best[-1:]]))       # shifted previous optimum
+    assert not np.array_equal(U2[1], U[1])                                        # fresh draws
+    assert u2.shape == (3,)
+    # the host never touches the candidate tensor: a step is far cheaper than sampling on the host
+    mpc_big = rv.MPC(N=20, K=4096, device_sampling=True)
+    st, _ = rv.synthetic_problem(1, 20)
+    for _ in range(5):
+        mpc_big.step(st)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        mpc_big.step(st)
+    per_step = (time.perf_counter() - t0) / 50
+    assert per_step < 2e-3, per_step
+    mpc.close(); mpc_big.close()
+
+
 def test_error_behaviour(rv):
     with pytest.raises(rv.RovmpcError):
         rv.Engine(rv.MPCConfig(N=0, K=4))
