@@ -83,7 +83,9 @@ template <typename T> struct RolloutArgs {
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
     unsigned magic_3n;            // floor(2^32 / (3N)) + 1: g / (3N) == umulhi(g, magic) for g < 2^16
     // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
-    unsigned long long *ticket;   // monotone arrival counter, never reset (nblocks per launch)
+    unsigned long long *ticket;   // (unused since the tagged-granule hand-off)
+    unsigned long long *granules; // [3][nblocks]: {epoch << 32 | 32 bits} of cost hi, cost lo, winning lane -- the data is the flag
+    unsigned epoch;               // launch counter of the handle, never 0: tag of this launch's granules
     double *result;               // [5 + 2(N+1)]
     long long *slots;             // [world][R] order-preserving int64 image (sharded step) or null
     long long k_offset;
@@ -147,6 +149,14 @@ RV_DEV void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RE
 RV_DEV void st_agent(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The workgroup's best as three tagged granules (epoch << 32 | 32 payload bits): cost high word, cost low word,
+// winning lane.  The reader takes a workgroup's record only when all three tags equal this launch's epoch.
+RV_DEV void publish_best(unsigned long long *granules, int nblocks, unsigned epoch, double cost, unsigned lane) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(cost), tag = (unsigned long long)epoch << 32;
+    st_agent(granules + blockIdx.x, tag | (bits >> 32));
+    st_agent(granules + nblocks + blockIdx.x, tag | (bits & 0xffffffffULL));
+    st_agent(granules + 2 * (size_t)nblocks + blockIdx.x, tag | lane);
+}
 RV_DEV double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -156,7 +166,7 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 // (input of the single all-reduce(min) of the candidate-sharded step).  `scratch` = 16
 // doubles of LDS.
 template <typename T>
-RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, const double *blk_traj, int nblocks,
+RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, const double *blk_traj, int nblocks,
                             const T *U, int N, int CK, int NT, double *result, long long k_offset,
                             long long *slots, int rank, int world, double *scratch,
                             const double *plant_next, double *plant_state, int plant_feedback,
@@ -171,7 +181,29 @@ RV_DEV void argmin_epilogue(const double *blk_cost, const long long *blk_idx, co
         const bool better = (oJ < Jd) | ((oJ == Jd) & (ok < kk));
         Jd = better ? oJ : Jd; kk = better ? ok : kk;
     };
-    for (int b = tid; b < nblocks; b += NT) take(ld_agent(&blk_cost[b]), ld_agent(&blk_idx[b]));
+    // Sweep (cdna_hip_programming.md G16, form R2: the data is the flag): every workgroup publishes its best as
+    // three 8-byte granules tagged with this launch's epoch, after draining the write-through stores of its
+    // trajectory.  This workgroup (number 0: the first dispatched, done before the stragglers) re-reads, with
+    // agent-scope loads, the granules it has not yet seen complete, until none is pending -- no ticket counter, no
+    // fence, and the other workgroups leave as soon as they have published.
+    {
+        int j = 0;
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            bool pending = false;
+            for (;;) {
+                const int b = tid + j * NT;
+                if (b >= nblocks) break;
+                const unsigned long long g0 = ld_agent(granules + b), g1 = ld_agent(granules + nblocks + b),
+                                         g2 = ld_agent(granules + 2 * (size_t)nblocks + b);
+                if ((unsigned)(g0 >> 32) != epoch || (unsigned)(g1 >> 32) != epoch || (unsigned)(g2 >> 32) != epoch) { pending = true; break; }
+                const double cost = __longlong_as_double((long long)((g0 << 32) | (g1 & 0xffffffffULL)));
+                take(cost, (long long)b * CK + (long long)(g2 & 0xffffffffULL));
+                ++j;
+            }
+            if (!__syncthreads_or(pending)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) take(__shfl_down(Jd, off, 64), __shfl_down(kk, off, 64));
     if ((tid & 63) == 0) { sJ[tid >> 6] = Jd; sK[tid >> 6] = kk; }
     __syncthreads();
@@ -985,6 +1017,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(5);
     // ---- phase 5: J_k, block arg-min, outputs ---------------------------------------------
     const bool fast_tail = a.result && !a.traj_all && N + 1 <= 64;
+    double &s_best_J = *reinterpret_cast<double *>(reinterpret_cast<char *>(smem) + 16);   // header bytes 16..23
     if (tid < 64) {
         const int c = tid;
         double Jd = __builtin_inf();
@@ -1020,15 +1053,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         } else {
             for (int off = 32; off > 0; off >>= 1) take(__shfl_down(Jd, off, 64), __shfl_down(kk, off, 64));
         }
-        if (c == 0) {
-            st_agent(&a.blk_cost[blockIdx.x], Jd);
-            st_agent(&a.blk_idx[blockIdx.x], kk);
-            *s_best_c = (int)(kk - k0);
-        }
+        if (c == 0) *s_best_c = (int)(kk - k0);
         if (fast_tail) {
-            // the common case: this wave alone hands the workgroup's best over (lane 0 holds it after the reduction) --
-            // trajectory stores, drain, ticket -- and the other waves meet it at ONE barrier to learn whether the
-            // workgroup is the last to arrive
+            // the common case: this wave alone hands the workgroup's best over (lane 0 holds it after the reduction):
+            // trajectory stores (write-through), drain, then the three tagged granules
             const int cb = __builtin_amdgcn_readfirstlane((int)(kk - k0));
             double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
             if (c <= N) {
@@ -1036,10 +1064,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 st_agent(&bt[2 * c + 1], (double)RV_PL(sY, 1, c, cb));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (c == 0) {
-                const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_best_c[1] = ((old + 1ULL) % (unsigned long long)a.nblocks) == 0ULL;
-            }
+            if (c == 0) publish_best(a.granules, a.nblocks, a.epoch, Jd, (unsigned)cb);
+        } else if (c == 0) {
+            s_best_J = Jd;
         }
     }
     RV_STAMP(14);
@@ -1062,32 +1089,20 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     RV_STAMP(6);
     if (!a.result) return;
-    int *s_last = s_best_c + 1;
     if (!fast_tail) {
 
-    // ---- arg-min epilogue in the last workgroup to arrive ------------------------------------
-    // Hand-off (cdna_hip_programming.md G16, counter form): every handed-off byte is stored
-    // write-through at agent scope (sc1), every storing wave drains its stores, the workgroup
-    // meets at a barrier, ONE lane takes a ticket; the workgroup that draws the last ticket
-    // acquires at agent scope and reads with agent-scope (sc1) loads.  No assumption on
-    // dispatch order or XCD placement.  The ticket counter is monotone (never reset): every
-    // launch of this handle adds exactly gridDim.x.
+    // ---- arg-min epilogue in workgroup 0 ---------------------------------------------------------
+    // Hand-off (cdna_hip_programming.md G16, form R2): every handed-off byte is stored write-through at
+    // agent scope (sc1), the storing wave(s) drain, then ONE lane publishes the workgroup's best as
+    // granules tagged with the launch epoch; workgroup 0 sweeps the granules with agent-scope loads
+    // until all carry the epoch.  No assumption on dispatch order, timing or XCD placement.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        const unsigned long long old = __hip_atomic_fetch_add(a.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = ((old + 1ULL) % (unsigned long long)a.nblocks) == 0ULL;
-    }
-    __syncthreads();
+    if (tid == 0) publish_best(a.granules, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c);
     }
     RV_STAMP(7);
-    if (!*s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    argmin_epilogue<T>(a.blk_cost, a.blk_idx, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
+    if (blockIdx.x != 0) return;
+    argmin_epilogue<T>(a.granules, a.epoch, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
                        a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback,
                        a.flag_consumed, a.consumed_need, a.flag_rolled, a.rolled_seq);
 }

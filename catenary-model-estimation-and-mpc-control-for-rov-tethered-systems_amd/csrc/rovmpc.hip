@@ -48,6 +48,8 @@ struct rovmpc_handle {
     double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
     long long *d_blk_idx = nullptr;
     unsigned long long *d_ticket = nullptr;
+    unsigned long long *d_granules = nullptr;  // [3][max_blocks] tagged hand-off granules
+    unsigned *epoch_ctr = nullptr;            // launches issued (host counter; tag of the next launch = ++*epoch_ctr, never 0)
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
     const unsigned long long *arg_flag_consumed = nullptr;   // hand-off flags of the step being enqueued (native collective)
     unsigned long long *arg_flag_rolled = nullptr;
@@ -301,6 +303,9 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
     CR(hipMalloc(&h->d_k, sizeof(RolloutConsts<double>)));
     CR(hipMalloc((void **)&h->d_ticket, sizeof(unsigned long long)));
+    CR(hipMalloc((void **)&h->d_granules, (size_t)3 * max_blocks * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_granules, 0, (size_t)3 * max_blocks * sizeof(unsigned long long)));
+    h->epoch_ctr = new unsigned(0);
     CR(hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
 #ifdef ROVMPC_STAMPS
     CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
@@ -320,8 +325,10 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_ticket, h->d_stamps};
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_ticket, h->d_stamps,
+                    h->d_granules};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h->epoch_ctr;
     if (h->h_result) (void)hipHostFree(h->h_result);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -637,6 +644,9 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
     a.ticket = h->d_ticket;
+    a.granules = h->d_granules;
+    if (++*h->epoch_ctr == 0) ++*h->epoch_ctr;      // never 0 (the granules start zeroed)
+    a.epoch = *h->epoch_ctr;
     a.NT = h->NT; a.nblocks = h->nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
     a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
