@@ -86,6 +86,8 @@ template <typename T> struct RolloutArgs {
     unsigned long long *ticket;   // (unused since the tagged-granule hand-off)
     unsigned long long *granules; // [3][nblocks]: {epoch << 32 | 32 bits} of cost hi, cost lo, winning lane -- the data is the flag
     unsigned epoch;               // launch counter of the handle, never 0: tag of this launch's granules
+    int sweeper;                  // workgroup that sweeps: 0 when the grid is one round of workgroups (first dispatched, first
+                                  // done, already polling when the stragglers publish), else the last (see argmin_epilogue)
     double *result;               // [5 + 2(N+1)]
     long long *slots;             // [world][R] order-preserving int64 image (sharded step) or null
     long long k_offset;
@@ -183,9 +185,10 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
     };
     // Sweep (cdna_hip_programming.md G16, form R2: the data is the flag): every workgroup publishes its best as
     // three 8-byte granules tagged with this launch's epoch, after draining the write-through stores of its
-    // trajectory.  This workgroup (number 0: the first dispatched, done before the stragglers) re-reads, with
-    // agent-scope loads, the granules it has not yet seen complete, until none is pending -- no ticket counter, no
-    // fence, and the other workgroups leave as soon as they have published.
+    // trajectory.  This workgroup (number 0 when the whole grid is resident at once; otherwise the LAST one of the
+    // grid, dispatched last, so that it never sits on a CU slot while earlier rounds of workgroups still queue for
+    // one -- measured: workgroup 0 as the sweeper cost a whole round at C3's two-round launch) re-reads, with agent-scope loads, the granules it has not yet seen complete, until none
+    // is pending -- no ticket counter, no fence, and the other workgroups leave as soon as they have published.
     {
         int j = 0;
         for (unsigned spins = 0; spins < (1u << 22); ++spins) {
@@ -1091,17 +1094,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     if (!a.result) return;
     if (!fast_tail) {
 
-    // ---- arg-min epilogue in workgroup 0 ---------------------------------------------------------
+    // ---- arg-min epilogue in the sweeping workgroup ------------------------------------------------
     // Hand-off (cdna_hip_programming.md G16, form R2): every handed-off byte is stored write-through at
     // agent scope (sc1), the storing wave(s) drain, then ONE lane publishes the workgroup's best as
-    // granules tagged with the launch epoch; workgroup 0 sweeps the granules with agent-scope loads
+    // granules tagged with the launch epoch; one workgroup (a.sweeper) sweeps the granules with agent-scope loads
     // until all carry the epoch.  No assumption on dispatch order, timing or XCD placement.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) publish_best(a.granules, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c);
     }
     RV_STAMP(7);
-    if (blockIdx.x != 0) return;
+    if ((int)blockIdx.x != a.sweeper) return;
     argmin_epilogue<T>(a.granules, a.epoch, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
                        a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback,
                        a.flag_consumed, a.consumed_need, a.flag_rolled, a.rolled_seq);

@@ -43,6 +43,7 @@ struct rovmpc_handle {
     bool has_rtab = false;
     // launch geometry / workspace
     int CK = 0, nblocks = 0, NT = 0;
+    int n_cu = 256;                  // compute units of the device (multiProcessorCount)
     size_t lds_bytes = 0, esz = 8;
     void *d_U = nullptr, *d_J = nullptr, *d_traj_all = nullptr;
     double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
@@ -216,13 +217,13 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
     // the per-node geometry phase is a single round
     int items = cfg->N * h->CK;
     h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
-    if (strict && model == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
+    if (strict) {
         hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+    }
+    if (strict && model == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
         int ck = 0, nt = 0;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess &&
-            throughput_geometry(h, prop.multiProcessorCount, &ck, &nt)) {
-            h->CK = ck; h->NT = nt;
-        }
+        if (throughput_geometry(h, h->n_cu, &ck, &nt)) { h->CK = ck; h->NT = nt; }
     }
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     if (cfg->threads_per_block > 0) h->NT = cfg->threads_per_block;
@@ -645,6 +646,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
     a.ticket = h->d_ticket;
     a.granules = h->d_granules;
+    a.sweeper = h->nblocks <= h->n_cu ? 0 : h->nblocks - 1;
     if (++*h->epoch_ctr == 0) ++*h->epoch_ctr;      // never 0 (the granules start zeroed)
     a.epoch = *h->epoch_ctr;
     a.NT = h->NT; a.nblocks = h->nblocks;
