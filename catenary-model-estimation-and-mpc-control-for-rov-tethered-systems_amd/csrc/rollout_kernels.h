@@ -191,7 +191,8 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
     // is pending -- no ticket counter, no fence, and the other workgroups leave as soon as they have published.
     {
         int j = 0;
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+        const unsigned long long give_up = wall_clock64() + 6000000000ULL;      // 60 s of the 100 MHz clock
+        for (unsigned it = 1;; ++it) {
             bool pending = false;
             for (;;) {
                 const int b = tid + j * NT;
@@ -204,6 +205,10 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
                 ++j;
             }
             if (!__syncthreads_or(pending)) break;
+            if ((it & 1023u) == 0 && __syncthreads_or(wall_clock64() > give_up)) {   // some workgroup never published: a NaN cost says so
+                Jd = __builtin_nan(""); kk = 0;
+                break;
+            }
             __builtin_amdgcn_s_sleep(4);
         }
     }
