@@ -65,8 +65,6 @@ template <typename T> struct RolloutArgs {
     const T *Rtab;            // [N][9] (VT_TABLE)
     T *J;                     // [K]
     T *traj_all;              // [K][N+1][2] or null
-    double *blk_cost;         // [nblocks]
-    long long *blk_idx;       // [nblocks]
     double *blk_traj;         // [nblocks][N+1][2]
     int N, K, CK, M, n_th, n_ga, prev_mode, integrator, debug, fmap;
     // sharded step with the library's own collective: GPU-side hand-off of slot row `rank` (null: none).
@@ -74,7 +72,7 @@ template <typename T> struct RolloutArgs {
     const unsigned long long *flag_consumed;
     unsigned long long *flag_rolled;
     unsigned long long consumed_need, rolled_seq;
-    // closed loop: the last workgroup also applies the plant update for the NEXT step (null: no update)
+    // closed loop: the sweeping workgroup also applies the plant update for the NEXT step (null: no update)
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
     int plant_feedback;           // 1: keep the model's own (theta, gamma) = first predicted node of this step's winner
@@ -82,8 +80,7 @@ template <typename T> struct RolloutArgs {
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
     unsigned magic_3n;            // floor(2^32 / (3N)) + 1: g / (3N) == umulhi(g, magic) for g < 2^16
-    // arg-min epilogue (run by the last workgroup to finish; null result = costs only)
-    unsigned long long *ticket;   // (unused since the tagged-granule hand-off)
+    // arg-min epilogue (run by the sweeping workgroup; null result = costs only)
     unsigned long long *granules; // [3][nblocks]: {epoch << 32 | 32 bits} of cost hi, cost lo, winning lane -- the data is the flag
     unsigned epoch;               // launch counter of the handle, never 0: tag of this launch's granules
     int sweeper;                  // workgroup that sweeps: 0 when the grid is one round of workgroups (first dispatched, first

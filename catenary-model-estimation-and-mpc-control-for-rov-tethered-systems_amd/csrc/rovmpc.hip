@@ -46,9 +46,7 @@ struct rovmpc_handle {
     int n_cu = 256;                  // compute units of the device (multiProcessorCount)
     size_t lds_bytes = 0, esz = 8;
     void *d_U = nullptr, *d_J = nullptr, *d_traj_all = nullptr;
-    double *d_state = nullptr, *d_blk_cost = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
-    long long *d_blk_idx = nullptr;
-    unsigned long long *d_ticket = nullptr;
+    double *d_state = nullptr, *d_blk_traj = nullptr, *d_result = nullptr;
     unsigned long long *d_granules = nullptr;  // [3][max_blocks] tagged hand-off granules
     unsigned *epoch_ctr = nullptr;            // launches issued (host counter; tag of the next launch = ++*epoch_ctr, never 0)
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
@@ -292,8 +290,6 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc(&h->d_U, (size_t)cfg->K * cfg->N * 3 * h->esz));
     CR(hipMalloc(&h->d_J, (size_t)cfg->K * h->esz));
     CR(hipMalloc((void **)&h->d_state, ROVMPC_STATE_LEN * sizeof(double)));
-    CR(hipMalloc((void **)&h->d_blk_cost, max_blocks * sizeof(double)));
-    CR(hipMalloc((void **)&h->d_blk_idx, max_blocks * sizeof(long long)));
     CR(hipMalloc((void **)&h->d_blk_traj, (size_t)max_blocks * (cfg->N + 1) * 2 * sizeof(double)));
     CR(hipMalloc((void **)&h->d_result, R * sizeof(double)));
     CR(hipHostMalloc((void **)&h->h_result, R * sizeof(double), hipHostMallocDefault));
@@ -303,11 +299,9 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
     CR(hipMalloc(&h->d_k, sizeof(RolloutConsts<double>)));
-    CR(hipMalloc((void **)&h->d_ticket, sizeof(unsigned long long)));
     CR(hipMalloc((void **)&h->d_granules, (size_t)3 * max_blocks * sizeof(unsigned long long)));
     CR(hipMemset(h->d_granules, 0, (size_t)3 * max_blocks * sizeof(unsigned long long)));
     h->epoch_ctr = new unsigned(0);
-    CR(hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
 #ifdef ROVMPC_STAMPS
     CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
     CR(hipMemset(h->d_stamps, 0, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
@@ -325,8 +319,8 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev) (void)hipEventDestroy(e);
-    void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_cost, h->d_blk_idx, h->d_blk_traj,
-                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_ticket, h->d_stamps,
+    void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
+                    h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
                     h->d_granules};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h->epoch_ctr;
@@ -604,9 +598,6 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
         else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
     }
     if (const char *why = configure_geometry(h, h->model_kind)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
-    // the ticket counter counts modulo the grid size: restart it with the new geometry
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemset(h->d_ticket, 0, sizeof(unsigned long long)));
     h->has_model = true;
     return ROVMPC_OK;
 }
@@ -637,14 +628,13 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.code_th = h->d_code_th; a.code_ga = h->d_code_ga;
     a.consts = (const T *)h->d_consts; a.Rtab = (const T *)h->d_Rtab;
     a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
-    a.blk_cost = h->d_blk_cost; a.blk_idx = h->d_blk_idx; a.blk_traj = h->d_blk_traj;
+    a.blk_traj = h->d_blk_traj;
     a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
     a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags; a.fmap = c.feature_map;
     a.used_planes = h->used_planes;
     a.ck_shift = 0;
     while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
-    a.ticket = h->d_ticket;
     a.granules = h->d_granules;
     a.sweeper = h->nblocks <= h->n_cu ? 0 : h->nblocks - 1;
     if (++*h->epoch_ctr == 0) ++*h->epoch_ctr;      // never 0 (the granules start zeroed)
@@ -1439,7 +1429,7 @@ extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, 
     const size_t R = rovmpc_result_len(h);
     const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * h->esz;
     if (!h->comm) {
-        // one GPU: the plant update of step i + 1 rides on the epilogue of step i (last workgroup), so the
+        // one GPU: the plant update of step i + 1 rides on the epilogue of step i (sweeping workgroup), so the
         // loop is back-to-back rollout kernels; only step 0 needs the stand-alone update
         hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
         HIPCHK(h, hipGetLastError());
