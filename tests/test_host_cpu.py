@@ -49,6 +49,32 @@ def test_config_struct_matches_c_layout():
         assert getattr(py, f) == getattr(c, f), f
 
 
+def test_config_fields_in_header_order():
+    """The ctypes mirror lists the fields of rovmpc_config in the header's order and types (int32 block, doubles)."""
+    from rovmpc._lib import Config
+    hdr = open(os.path.join(ROOT, "include", "rovmpc.h")).read()
+    body = re.search(r"typedef struct rovmpc_config \{(.*?)\} rovmpc_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(int32_t|double)\s+(.+)", decl.strip(), re.S)
+        if not m:
+            continue
+        for name in m.group(2).split(","):
+            name = name.strip()
+            arr = re.match(r"(\w+)\[(\d+)\]", name)
+            fields.append((arr.group(1) if arr else name, m.group(1), int(arr.group(2)) if arr else 1))
+    mirror = []
+    for name, ctype in Config._fields_:
+        if ctype is ctypes.c_int32:
+            mirror.append((name, "int32_t", 1))
+        elif ctype is ctypes.c_double:
+            mirror.append((name, "double", 1))
+        else:
+            mirror.append((name, "double", ctypes.sizeof(ctype) // 8))
+    assert fields == mirror
+
+
 @pytest.mark.skipif(not _no_gpu(), reason="needs a box without a GPU")
 def test_no_gpu_is_a_loud_error_not_a_fallback():
     with pytest.raises(rovmpc.RovmpcError) as ei:
