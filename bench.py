@@ -4,7 +4,11 @@
 per step (configs[3] at 8 GPUs: K=32768 = 8 x 4096).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 is a plain command: when no rank environment is present the process
+starts N rank processes itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a CHILD, before anything here touches the GPU), relays rank 0's JSON line and exits with the
+children's status.  Launched under torch.distributed.run directly (RANK/WORLD_SIZE set) it is a rank.
 
 A "step" = one full MPC step on device-resident inputs: fused rollout kernel + arg-min epilogue
 (+ all-reduce(min) + select when sharded).  Inputs are resident in HBM before the timed region;
@@ -12,8 +16,12 @@ a pool of independent synthetic candidate batches is cycled so no step re-reads 
 step's batch.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +29,114 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "catenary-model-estimation-and-mpc-control-for-rov-tethered-systems_amd")
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec), reported as context only
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec): 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
+PROFILE_TAG = "r02"             # profiles/<tag>_pmc_summary.json is the PMC pass the roofline block may quote
 
+
+def kernel_sources_sha16():
+    """Hash of the sources the rollout kernel is built from; stamped into every profile summary so a
+    committed PMC pass is only quoted for the kernel it was taken on."""
+    h = hashlib.sha256()
+    for rel in ("csrc/rollout_kernels.h", "csrc/device_math.h", "csrc/rovmpc.hip", "csrc/util_kernels.h"):
+        with open(os.path.join(PKG, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--K", type=int, default=4096, help="candidates per GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dt", type=float, default=0.0, help="horizon step [s] (0 = the library default, 1/60)")
+    ap.add_argument("--ck", type=int, default=0, help="candidates per workgroup (0 = auto)")
+    ap.add_argument("--nt", type=int, default=0, help="threads per workgroup (0 = auto)")
+    ap.add_argument("--pools", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the ranks; gloo = rehearsal of the N > 1 path without RCCL "
+                         "(the slot buffer crosses the host)")
+    ap.add_argument("--devices", default="", help="comma list: device ordinal of each local rank (default: the local rank); "
+                                                  "'0,0' rehearses two ranks on one GPU (gloo only: RCCL refuses a shared GPU)")
+    ap.add_argument("--protocol-only", action="store_true",
+                    help="no GPU, no rollout: every rank fabricates its record; exercises launcher, rendezvous, "
+                         "pack / all-reduce(min) / select and the JSON relay (CPU test of the N > 1 plumbing)")
+    ap.add_argument("--torch-collective", action="store_true", help="use torch.distributed for the all-reduce instead of the library's own RCCL call")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="single GPU rehearsal of the sharded step: nccl world of 1 with the all-reduce kept")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent MPC steps in flight on one GPU (one engine handle + HIP stream each); 1 = strictly sequential steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-pipelined-extra", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip batched / worst-path / dt=0.05 / closed-loop extras")
+    ap.add_argument("--closed-loop", type=int, default=-1,
+                    help="steps of the closed-loop extra (BASELINE config 5, Rov_traj_gen case 12); -1 = 10000 at the default size, 0 = off")
+    ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
+    ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows) | gen2 | gen3")
+    ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
+    ap.add_argument("--fallback-reason", default="", help=argparse.SUPPRESS)   # set by the parent when it re-launches
+    return ap
+
+
+# ---- parent: start the ranks as children (never exec, never touch the GPU here) --------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(argv, n, timeout):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:                                     # exactly the process group started above
+            os.killpg(proc.pid, signal.SIGTERM)
+            time.sleep(5)
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        rc = 124
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+    return rc, line, out or ""
+
+
+def launch_ranks(args, argv):
+    rc, line, out = _run_ranks(argv, args.gpus, args.launch_timeout)
+    if (rc != 0 or line is None) and rc != 124 and not args.torch_collective and not args.protocol_only and args.backend == "nccl":
+        # the library's own RCCL path failed as a whole (a rank died): one more run on torch.distributed's
+        # collective, with the reason carried into the JSON line -- never a silent switch
+        why = f"native RCCL run exited with code {rc}" + ("" if line else " without a result line")
+        print(f"[bench] {why}; re-running with --torch-collective", file=sys.stderr)
+        rc, line, out = _run_ranks(argv + ["--torch-collective", "--fallback-reason", why], args.gpus, args.launch_timeout)
+    if line is None:
+        sys.stderr.write(out[-4000:])
+        print(f"[bench] ranks produced no result line (exit code {rc})", file=sys.stderr)
+        sys.exit(rc or 1)
+    print(line)
+    sys.exit(rc)
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------------------------
 
 def cpu_baseline(N, seconds_budget=12.0):
     """The oracle ("port" of the reference's per-row Python path) timed on this host, one core:
@@ -64,54 +176,109 @@ def cpu_baseline(N, seconds_budget=12.0):
             "vectorized_sample": f"oracle.rollout_vec, {reps} x (K=4096, N={N}), 1 core"}
 
 
+# ---- protocol-only ranks (no GPU): the N > 1 plumbing under gloo -------------------------------------------------------
+
+def protocol_rank(args, world, rank):
+    """Every rank fabricates a record per step (cost and index a fixed function of (rank, step)), packs it into its row of
+    the [world][R] int64 slot image, ONE all-reduce(min), select -- the host statement of the sharded step.  Checks that
+    every rank ends with the same record and that it is the lexicographic minimum; prints the same JSON shape."""
+    import torch
+    import torch.distributed as dist
+    from rovmpc.sharded import ShardedMPC
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = 5 + 2 * (args.N + 1)
+    step_no = [0]
+
+    def fabricated(r, i):
+        g = np.random.default_rng(1000 * i + r)
+        rec = g.standard_normal(R)
+        rec[0] = float((7 * i + 3 * r) % world) + 0.25          # ties across ranks happen: the lower index must win
+        rec[1] = float(r * args.K + int(g.integers(0, args.K)))
+        return rec
+
+    smpc = ShardedMPC(local_solver=lambda: torch.tensor(fabricated(rank, step_no[0])), rank=rank, world=world,
+                      K_total=world * args.K)
+    ok = True
+    for i in range(args.warmup):
+        step_no[0] = i; smpc.step_host()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_no[0] = i
+        rec = smpc.step_host().numpy()
+        want = min((fabricated(r, i) for r in range(world)), key=lambda v: (v[0], v[1]))
+        ok = ok and np.array_equal(rec, want)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    allrec = [None] * world
+    dist.all_gather_object(allrec, (rec.tolist(), bool(ok)))
+    if rank == 0:
+        print(json.dumps({
+            "metric": metric_name(args, world), "value": None, "unit": "horizon-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "protocol-only: fabricated per-rank records, no rollout (plumbing check, not a measurement)",
+            "config": {"workload": "protocol-only", "N": args.N, "K_per_gpu": args.K, "K_global": world * args.K,
+                       "collective": "torch.distributed all_reduce(MIN) (gloo)", "collective_fallback_reason": None},
+            "ranks_agree": all(r[0] == allrec[0][0] for r in allrec),
+            "records_are_the_global_min": all(r[1] for r in allrec)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def metric_name(args, world):
+    if (args.N, args.K) == (20, 4096):
+        return "MPC rollouts/sec (horizon-steps/sec) at N=20, K=4096; 1/2/4/8 GPU"      # BASELINE.json's metric, verbatim
+    return f"MPC rollouts/sec (horizon-steps/sec) at N={args.N}, K={args.K}; {world} GPU"
+
+
+# ---- a rank -------------------------------------------------------------------------------------------------------------
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--N", type=int, default=20)
-    ap.add_argument("--K", type=int, default=4096, help="candidates per GPU")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--ck", type=int, default=0, help="candidates per workgroup (0 = auto)")
-    ap.add_argument("--nt", type=int, default=0, help="threads per workgroup (0 = auto)")
-    ap.add_argument("--pools", type=int, default=8)
-    ap.add_argument("--torch-collective", action="store_true", help="use torch.distributed for the all-reduce instead of the library's own RCCL call")
-    ap.add_argument("--force-collective", action="store_true",
-                    help="single GPU rehearsal of the sharded step: nccl world of 1 with the all-reduce kept")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent MPC steps in flight on one GPU (one engine handle + HIP stream each); 1 = strictly sequential steps")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-pipelined-extra", action="store_true")
-    ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
-    ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows) | gen2 | gen3")
-    ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
-    args = ap.parse_args()
+    args = build_parser().parse_args()
+    have_rank_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_rank_env:
+        launch_ranks(args, sys.argv[1:])          # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.protocol_only:
+        if os.environ.get("ROVMPC_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: this rank dies before the rendezvous
+            raise SystemExit(3)
+        return protocol_rank(args, world, rank)
 
     import torch
     import rovmpc
     from rovmpc.sharded import ShardedMPC
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    devs = [int(v) for v in args.devices.split(",")] if args.devices else None
+    device = devs[local_rank] if devs else local_rank
+    if devs and len(set(devs)) < len(devs) and args.backend == "nccl" and world > 1:
+        raise SystemExit("--devices maps two ranks to one GPU: RCCL refuses that (Duplicate GPU detected); use --backend gloo")
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
     dist = None
     if world > 1 or args.force_collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=local_rank,
+    cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, device=device,
                            candidates_per_block=args.ck, threads_per_block=args.nt, force_interpreter=args.interp, debug_flags=args.debug_flags)
+    if args.dt > 0:
+        cfg.dt = args.dt
     S = max(1, args.streams) if (world == 1 and not args.force_collective) else 1
     model = rovmpc.default_model()
     if args.model == "jit-default":
-        model = rovmpc.DynamicsModel(model.mean, model.scale, model.expr_theta + " + 0.0*x0", model.expr_gamma)
+        cfg.no_builtin = True               # the reference rows through the hiprtc route
     elif args.model == "gen3":          # second-order generation on the features_dd map (dd_cluster.py)
         model = rovmpc.generation3_model()
         cfg.feature_map = rovmpc.FEATURES_GEN3
@@ -136,19 +303,23 @@ def main():
     streams = [stream] if S == 1 else [torch.cuda.Stream(device=dev, priority=-(j % 2)) for j in range(S)]
     smpc = None
     collective = None
+    fallback_reason = args.fallback_reason or None
     if world > 1 or args.force_collective:
-        if not args.torch_collective:
-            try:        # RCCL called from the library (one C call per step)
+        if not args.torch_collective and args.backend == "nccl":
+            try:        # RCCL called from the library (one C call per step); every rank agrees on the outcome inside
                 from rovmpc.sharded import NativeShardedMPC
                 smpc = NativeShardedMPC(eng, rank=rank, world=world)
                 collective = "ncclAllReduce(min) issued by librovmpc"
-            except Exception as exc:                      # noqa: BLE001 -- fall back, never fail the bench
+            except Exception as exc:                      # noqa: BLE001 -- recorded in the JSON line, see collective_fallback_reason
+                fallback_reason = f"native RCCL set-up failed: {exc}"
                 if rank == 0:
-                    print(f"[bench] native RCCL path unavailable ({exc}); using torch.distributed", file=sys.stderr)
+                    print(f"[bench] {fallback_reason}; using torch.distributed", file=sys.stderr)
                 smpc = None
         if smpc is None:
-            smpc = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective)
-            collective = "torch.distributed all_reduce(MIN) (nccl backend = RCCL)"
+            smpc = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective,
+                              host_staged=(args.backend == "gloo"))
+            collective = ("torch.distributed all_reduce(MIN) (nccl backend = RCCL)" if args.backend == "nccl" else
+                          "torch.distributed all_reduce(MIN) (gloo, slot image staged through the host: rehearsal)")
     d_res = torch.empty((2 * S, R), dtype=torch.float64, device=dev)
 
     def one_step(i):
@@ -161,7 +332,7 @@ def main():
 
     def fence():
         if smpc is not None:
-            smpc.synchronize()
+            smpc.synchronize()                # raises if a GPU-side hand-off of any step gave up
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -189,7 +360,7 @@ def main():
     launches = [len(range(j, args.steps, S)) for j in range(S)]
     region_ms = sum(a_.elapsed_time(b_) / max(n_, 1) for a_, b_, n_ in zip(ev0, ev1, launches)) / S * args.steps
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last = rec.cpu().numpy()
@@ -212,13 +383,15 @@ def main():
         eng.timing_enable(0)
 
     if rank == 0:
+        import bench_extras
         units_per_step = world * args.K * args.N
         tag = ("C2" if (args.N, args.K, args.dtype) == (20, 4096, "f64") else
                "C3" if (args.N, args.K, args.dtype) == (50, 16384, "f32") else "other size")     # BASELINE.json configs
         esz = 8 if args.dtype == "f64" else 4
         alg_bytes = args.K * args.N * 3 * esz + args.K * esz          # controls in, costs out
+        sha = kernel_sources_sha16()
         out = {
-            "metric": "MPC rollouts/sec (horizon-steps/sec) at N=20, K=4096; 1/2/4/8 GPU",
+            "metric": metric_name(args, world),
             "value": units_per_step * args.steps / elapsed,
             "unit": "horizon-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,10 +405,12 @@ def main():
                        "model": f"{args.model}: {eng.model_path}",
                        "parallelism": f"candidate-sharded x{world}, 1 all-reduce(min)/step" if world > 1 else "single GPU",
                        "steps_in_flight": S if smpc is None else "rollout(i+1) overlaps all-reduce(i)",
-                       "collective": collective,
-                       "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
+                       "collective": collective, "collective_fallback_reason": fallback_reason,
+                       "backend": args.backend if dist is not None else None,
+                       "devices": devs, "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
             "best": {"cost": float(last[0]), "index": int(last[1])},
             "ranks_agree": ranks_agree,
+            "build": {"kernel_sources_sha16": sha},
         }
         if kavg_ms:
             achieved = alg_bytes / (kavg_ms * 1e-3) / 1e9
@@ -246,25 +421,11 @@ def main():
                                "kernel_event_pair_us": kev_ms * 1e3 if kev_ms else None,
                                "kernel_event_pair_min_us": kev_min_ms * 1e3 if kev_min_ms else None,
                                "algorithmic_bytes_per_launch": alg_bytes,
-                               "note": "fp64 VALU/latency-bound by construction (~2-3 kFLOP of transcendental work "
-                                       "per 24.4 B); see DESIGN.md"}
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs of this same command; MI355X_MICROARCH.md: KiB units, FETCH_SIZE reads half the
-        # bytes of a 16 B/lane coalesced stream on gfx950 -> doubled); only for the profiled workload.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if "roofline" in out and os.path.exists(pmc_path) and (args.N, args.K, args.dtype, world) == (20, 4096, "f64", 1):
-            pmc = json.load(open(pmc_path))
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                out["roofline"]["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, KiB)"
-            if "SQ_WAVE_CYCLES" in pmc and "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
-                # what actually bounds the kernel (same committed PMC passes): share of the waves' lifetime spent
-                # waiting (barriers, dependent latencies) vs issuing VALU
-                wc = pmc["SQ_WAVE_CYCLES"]["mean"]
-                out["roofline"]["wave_cycles_waiting_frac"] = pmc["SQ_WAIT_ANY"]["mean"] / wc
-                out["roofline"]["wave_cycles_valu_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc
-                if "SQ_INSTS_VALU" in pmc:
-                    out["roofline"]["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]["mean"]
+                               "binding_bound": "fp64-valu issue / dependent-chain latency (see valu_f64); HBM is the bound BASELINE.json "
+                                                "asks to be reported, not the one that limits this kernel (~2-3 kFLOP per 24.4 B)"}
+            if (args.N, args.K, args.dtype, world) == (20, 4096, "f64", 1) and args.model == "default" and args.debug_flags == 0:
+                bench_extras.attach_pmc(out["roofline"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json"), sha,
+                                        kavg_ms * 1e-3, FP64_VECTOR_PEAK_TFLOPS)
         if world == 1 and smpc is None and S == 1 and not args.no_pipelined_extra:
             # extra, not the headline: two independent MPC steps in flight on one GPU (second engine handle
             # on a high-priority stream = its own hardware queue), so one step's launch ramp / arg-min tail
@@ -273,6 +434,7 @@ def main():
             st2 = torch.cuda.Stream(device=dev, priority=-1)
             pair = [(eng, stream), (eng2, st2)]
             r2 = torch.empty((4, R), dtype=torch.float64, device=dev)
+
             def step2(i):
                 e, st = pair[i & 1]
                 e.step_device(d_state.data_ptr(), pools[i % args.pools].data_ptr(), r2[i & 3].data_ptr(), st.cuda_stream)
@@ -287,6 +449,9 @@ def main():
             out["two_steps_in_flight"] = {"value": units_per_step * args.steps / e2, "ms_per_step": 1e3 * e2 / args.steps,
                                           "note": "throughput with 2 independent steps overlapped on one GPU; `value` above is 1 in flight"}
             eng2.close()
+        default_size = (args.N, args.K, args.dtype, args.model) == (20, 4096, "f64", "default") and args.debug_flags == 0
+        if world == 1 and smpc is None and S == 1 and default_size and not args.no_extras:
+            bench_extras.run_extras(out, args, cfg, model, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.N)
         print(json.dumps(out))

@@ -1,0 +1,143 @@
+"""Extra keys of the bench line (rank 0, single GPU, default size only).  None of them is the headline `value`:
+they put the other regimes of the same kernel beside it so the headline is visibly not a best case.
+
+  roofline.valu_f64 / traffic   from the committed PMC passes, quoted only when they were taken on this kernel build
+  batched                       B independent C2 problems in one launch (rovmpc_step_batch_device)
+  worst_path                    C2 size on data that forces the checked sine and per-step sincos re-anchoring
+  dt_0p05                       C2 size at SURVEY section 8(d)'s dt = 0.05 s, with its best cost
+  closed_loop                   BASELINE config 5 on one GPU: T steps of Rov_traj_gen case 12, real-time factor
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+
+def attach_pmc(roof, pmc_path, sha, kernel_s, fp64_peak_tflops, n_simd=1024, clk_hz=2.4e9):
+    """HBM traffic and the fp64-VALU bound from rocprofv3 --pmc passes of this same command (tools/profile_round.sh).
+    The summary carries the hash of the kernel sources it was taken on; a summary of another build is NOT quoted."""
+    if not os.path.exists(pmc_path):
+        roof["traffic_source"] = f"none: {os.path.basename(pmc_path)} not present"
+        return
+    pmc = json.load(open(pmc_path))
+    meta = pmc.get("_meta", {})
+    src = f"profiles/{os.path.basename(pmc_path)}"
+    if meta.get("kernel_sources_sha16") != sha:
+        roof["traffic_source"] = (f"none: {src} was taken on kernel sources {meta.get('kernel_sources_sha16')} "
+                                  f"(commit {meta.get('commit')}), this build is {sha}")
+        return
+    roof["traffic_source"] = f"{src} (kernel sources {sha}, commit {meta.get('commit')}; FETCH_SIZE x2 + WRITE_SIZE, KiB)"
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # MI355X_MICROARCH.md: KiB units; FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream on gfx950
+        roof["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+    f64 = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"]
+    if all(k in pmc for k in f64) and kernel_s > 0:
+        fma, add, mul, trans = (pmc[k]["mean"] for k in f64)
+        flop = 64.0 * (2.0 * fma + add + mul + trans)            # lane slots of the wave-instructions, exec mask ignored
+        n64 = fma + add + mul + trans
+        v = {"achieved_tflops": flop / kernel_s / 1e12, "peak_tflops": fp64_peak_tflops,
+             "frac": flop / kernel_s / 1e12 / fp64_peak_tflops,
+             "f64_wave_instructions_per_launch": n64,
+             "note": "flop = 64 x (2 FMA + ADD + MUL + TRANS) wave-instructions per launch / this run's kernel time"}
+        if "SQ_INSTS_VALU" in pmc:
+            # issue slots: an fp64 wave-instruction holds its SIMD's vector issue 4 cycles (16 lanes/clk), any other 2
+            busy = (4.0 * n64 + 2.0 * max(pmc["SQ_INSTS_VALU"]["mean"] - n64, 0.0)) / (n_simd * kernel_s * clk_hz)
+            v["issue_busy_frac"] = busy
+            v["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]["mean"]
+        roof["valu_f64"] = v
+    if "SQ_WAVE_CYCLES" in pmc and "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
+        wc = pmc["SQ_WAVE_CYCLES"]["mean"]
+        roof["wave_cycles_waiting_frac"] = pmc["SQ_WAIT_ANY"]["mean"] / wc
+        roof["wave_cycles_valu_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc
+
+
+def _timed(fn, n, warm, sync):
+    for i in range(warm):
+        fn(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    sync()
+    return (time.perf_counter() - t0) / n
+
+
+def run_extras(out, args, cfg, model, dev):
+    import torch
+    import rovmpc
+    N, K = args.N, args.K
+    sync = torch.cuda.synchronize
+    stream = torch.cuda.current_stream().cuda_stream
+    n_rep = max(50, min(args.steps, 400))
+
+    # ---- batched: B problems per launch -----------------------------------------------------------------------------
+    eng = rovmpc.Engine(cfg, model)
+    R = eng.result_len
+    batched = []
+    for B in (8, 64):
+        states = np.empty((B, 16)); U = np.empty((B, K, N, 3), dtype=cfg.np_dtype)
+        for b in range(B):
+            states[b], U[b] = rovmpc.synthetic_problem(K, N, seed=777 + b, dtype=cfg.np_dtype)
+        d_states = torch.tensor(states, device=dev); d_U = torch.tensor(U, device=dev)
+        d_res = torch.empty((B, R), dtype=torch.float64, device=dev)
+        per = _timed(lambda i: eng.step_batch_device(B, d_states.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), stream),
+                     max(20, n_rep // (B // 4)), 5, sync)
+        # problem b's record must equal the single-problem launch on the same inputs, bit for bit
+        single = torch.empty(R, dtype=torch.float64, device=dev)
+        same = True
+        for b in (0, B - 1):
+            eng.step_device(d_states[b].data_ptr(), d_U[b].data_ptr(), single.data_ptr(), stream)
+            sync()
+            same = same and bool(torch.equal(single, d_res[b]))
+        batched.append({"B": B, "value": B * K * N / per, "ms_per_launch": 1e3 * per,
+                        "records_bit_equal_to_single_launches": same})
+        del d_U
+    out["batched"] = {"unit": "horizon-steps/s", "runs": batched,
+                      "note": "B independent C2-sized problems (own state, own candidates) per rovmpc_step_batch_device launch"}
+
+    # ---- worst path: the checked sine + full sincos on the theta chain -------------------------------------------------
+    state, U = rovmpc.synthetic_problem(K, N, dtype=cfg.np_dtype)
+    U = U.copy()
+    U[::16, N // 2, 0] = 3e10 * np.where(np.arange(0, K, 16) % 32 == 0, 1.0, -1.0)    # one huge control per workgroup
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    d_r = torch.empty(R, dtype=torch.float64, device=dev)
+    per = _timed(lambda i: eng.step_device(d_state.data_ptr(), d_U.data_ptr(), d_r.data_ptr(), stream), n_rep, 10, sync)
+    rec = d_r.cpu().numpy()
+    out["worst_path"] = {"value": K * N / per, "ms_per_step": 1e3 * per, "best": {"cost": float(rec[0]), "index": int(rec[1])},
+                         "note": "same size; one control of 3e10 mm/s in every 16th candidate puts every workgroup on the "
+                                 "range-checked sine and makes its theta wave re-anchor sincos(theta) by full evaluation"}
+    eng.close()
+
+    # ---- SURVEY's dt = 0.05 --------------------------------------------------------------------------------------------
+    cfg2 = rovmpc.MPCConfig(**{**cfg.__dict__, "dt": 0.05})
+    eng2 = rovmpc.Engine(cfg2, model)
+    state, U = rovmpc.synthetic_problem(K, N, dtype=cfg.np_dtype)
+    d_U = torch.tensor(U, device=dev)
+    per = _timed(lambda i: eng2.step_device(d_state.data_ptr(), d_U.data_ptr(), d_r.data_ptr(), stream), n_rep, 10, sync)
+    rec = d_r.cpu().numpy()
+    out["dt_0p05"] = {"value": K * N / per, "ms_per_step": 1e3 * per, "best": {"cost": float(rec[0]), "index": int(rec[1])},
+                      "note": "SURVEY 8(d)'s dt = 0.05 s: the delay recurrence of the chosen dgamma/dt row diverges "
+                              "(costs ~1e30, arg-min decided by rounding), which is why the headline uses dt = 1/60"}
+    eng2.close()
+
+    # ---- closed loop (BASELINE config 5 on one GPU) --------------------------------------------------------------------
+    T = args.closed_loop if args.closed_loop >= 0 else 10000
+    if T > 0:
+        from rovmpc.closed_loop import run_closed_loop
+        eng3 = rovmpc.Engine(cfg, model)
+        runs = {}
+        for mode, kw in (("launch_per_step", {"persistent": False}), ("persistent", {"persistent": True})):
+            try:
+                run_closed_loop(eng3, 12, min(T, 200), feedback=True, **kw)            # warm-up
+                rep = run_closed_loop(eng3, 12, T, feedback=True, **kw)
+                runs[mode] = {"us_per_step": 1e6 * rep.wall_s / rep.steps, "real_time_factor": rep.real_time_factor,
+                              "final_cost": float(rep.cost[-1])}
+            except rovmpc.RovmpcError as exc:
+                runs[mode] = {"error": str(exc)}
+        best = min((m for m in runs if "us_per_step" in runs[m]), key=lambda m: runs[m]["us_per_step"], default=None)
+        out["closed_loop"] = {"steps": T, "case": 12, "feedback": True, "K": K, "N": N,
+                              "mode": best, **(runs[best] if best else {}), "modes": runs,
+                              "note": "Rov_traj_gen case 12 (circle); (theta, gamma) of step i+1 = first predicted node of step "
+                                      "i's winner, so the steps are truly sequential; real_time_factor = steps * dt / wall"}
+        eng3.close()

@@ -72,6 +72,10 @@ template <typename T> struct RolloutArgs {
     const unsigned long long *flag_consumed;
     unsigned long long *flag_rolled;
     unsigned long long consumed_need, rolled_seq;
+    unsigned long long *slot_bad;     // use number of this slot whose row could NOT be written (select then reports NaN)
+    unsigned long long handoff_ticks; // give-up time of the hand-off waits, 100 MHz ticks
+    unsigned *err;                    // host-mapped error word of the handle (ERR_* bits), read by rovmpc_comm_sync / rovmpc_device_status
+    int inject;                       // test hooks (rovmpc_set_option): bit 0 = this launch does not publish its row
     // closed loop: the sweeping workgroup also applies the plant update for the NEXT step (null: no update)
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
@@ -141,6 +145,14 @@ RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restric
     return top;
 }
 
+// Bits of the handle's error word (host-mapped, written at system scope on the rare failure paths).
+constexpr unsigned ERR_WAIT_ROLLED = 1;   // a collective gave up waiting for its rollout's row
+constexpr unsigned ERR_CONSUMED    = 2;   // a rollout gave up waiting for the select that frees its slot row
+constexpr unsigned ERR_SWEEP       = 4;   // the arg-min sweep gave up waiting for a workgroup's record
+RV_DEV void raise_error(unsigned *err, unsigned bit) {
+    if (err) __hip_atomic_fetch_or(err, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- arg-min epilogue ----------------------------------------------------------------------
 // Agent-scope (sc1, write-through / L1-bypassing) accessors for the bytes one workgroup hands
 // to another inside a launch.
@@ -165,12 +177,11 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 // (input of the single all-reduce(min) of the candidate-sharded step).  `scratch` = 16
 // doubles of LDS.
 template <typename T>
-RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, const double *blk_traj, int nblocks,
-                            const T *U, int N, int CK, int NT, double *result, long long k_offset,
-                            long long *slots, int rank, int world, double *scratch,
-                            const double *plant_next, double *plant_state, int plant_feedback,
-                            const unsigned long long *flag_consumed, unsigned long long consumed_need,
-                            unsigned long long *flag_rolled, unsigned long long rolled_seq) {
+RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *granules, const double *blk_traj, const T *U,
+                            double *result, double *scratch) {
+    const int nblocks = a.nblocks, N = a.N, CK = a.CK, NT = a.NT, rank = a.rank, world = a.world;
+    long long *slots = a.slots;
+    const unsigned epoch = a.epoch;
     double *sJ = scratch;                                    // [8]
     long long *sK = reinterpret_cast<long long *>(scratch + 8);   // [8]
     const int tid = threadIdx.x, nw = (NT + 63) >> 6;
@@ -204,6 +215,7 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
             if (!__syncthreads_or(pending)) break;
             if ((it & 1023u) == 0 && __syncthreads_or(wall_clock64() > give_up)) {   // some workgroup never published: a NaN cost says so
                 Jd = __builtin_nan(""); kk = 0;
+                if (tid == 0) raise_error(a.err, ERR_SWEEP);
                 break;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -223,37 +235,51 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
-    if (flag_consumed) {
-        // the slot buffer is reused every few steps: its previous contents must have been read by that step's select
+    bool row_free = true;
+    if (a.flag_consumed) {
+        // the slot buffer is reused every few steps: its previous contents must have been read by that step's select.
+        // If that never happens (a failed collective) the row is NOT rewritten: the error word and the slot's
+        // bad-use mark make this step's global record a NaN and rovmpc_comm_sync an error.
+        int *s_ok = reinterpret_cast<int *>(scratch + 15);     // sK[7]: read by thread 0 only, before the last barrier
         if (tid == 0) {
-            for (long spin = 0; ld_agent(flag_consumed) < consumed_need && spin < (1L << 23); ++spin) __builtin_amdgcn_s_sleep(8);
+            const unsigned long long give_up = wall_clock64() + a.handoff_ticks;
+            bool ok = true;
+            while (ld_agent(a.flag_consumed) < a.consumed_need) {
+                if (wall_clock64() > give_up) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) { raise_error(a.err, ERR_CONSUMED); st_agent(a.slot_bad, a.rolled_seq); }
+            *s_ok = ok ? 1 : 0;
         }
         __syncthreads();
+        row_free = *s_ok != 0;
     }
     for (int i = tid; i < R; i += NT) {
         double v;
-        if (i == 0) v = Jbest;
-        else if (i == 1) v = (double)(kbest + k_offset);
+        if (i == 0) v = row_free ? Jbest : __builtin_nan("");
+        else if (i == 1) v = (double)(kbest + a.k_offset);
         else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
         else v = ld_agent(&bt[i - 5]);
         result[i] = v;
-        if (slots) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
+        if (slots && row_free) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
     }
-    if (slots) {
+    if (slots && row_free) {
         for (int i = tid; i < world * R; i += NT)
             if (i / R != rank) st_agent(&slots[i], 0x7fffffffffffffffLL);
     }
-    if (flag_rolled) {
+    if (a.flag_rolled && !(a.inject & 1)) {
         // publish: the row went out write-through at agent scope; once every wave's stores are acknowledged the
         // sequence number follows (the collective stream's wait kernel polls it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) st_agent(flag_rolled, rolled_seq);
+        if (tid == 0) st_agent(a.flag_rolled, a.rolled_seq);
     }
     // Closed loop on one GPU: the plant update of the next step (plant_update_kernel's rule) rides on this
     // workgroup -- every other workgroup has finished, nobody reads the state any more.
-    if (plant_next && tid < 16) {
-        if (!plant_feedback) {
+    if (a.plant_next && tid < 16) {
+        const double *plant_next = a.plant_next;
+        double *plant_state = a.plant_state;
+        if (!a.plant_feedback) {
             plant_state[tid] = plant_next[tid];
         } else if (tid < 12) {
             plant_state[tid] = plant_next[tid];
@@ -270,10 +296,10 @@ RV_DEV void argmin_epilogue(const unsigned long long *granules, unsigned epoch, 
 // In-kernel phase stamps exist only in the diagnostic library (make diag, -DROVMPC_STAMPS); the
 // product library contains none of this code.
 #ifdef ROVMPC_STAMPS
-#define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
-#define RV_STAMP_W(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)   // lane 0 of the calling wave
+#define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#define RV_STAMP_W(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)   // lane 0 of the calling wave
 // slot i <- HW_ID (hwreg 4: wave, simd, pipe, cu, sh, se) | XCC_ID (hwreg 20) << 32: which CU ran the workgroup
-#define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (i)] = \
+#define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = \
     (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
 #else
 #define RV_STAMP(i) do { } while (0)
@@ -319,6 +345,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const RolloutConsts<T> &kk = *a.k;
     const int tid = threadIdx.x, NT = a.NT;
     const int k0 = blockIdx.x * CK;
+    // Batched launch (rovmpc_step_batch_device): blockIdx.y = problem.  Every per-problem array is the single-problem
+    // array repeated B times; a problem's workgroups, granules, sweeper and record never touch another problem's.
+    const int prob = blockIdx.y;
+    const T *Ub = a.U + (size_t)prob * K * N * 3;
     const int nvalid = min(CK, K - k0);
     constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
     constexpr int NA = VT == ROVMPC_VT_COMPOSE ? NAX : 5;
@@ -341,7 +371,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(0);
     // state: declared here (the gamma lambdas capture it), loaded after the controls' loads are in flight
     T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
-    const double *sd = a.state;
+    const double *sd = a.state + (size_t)prob * ROVMPC_STATE_LEN;
 
     // Compiled-in model: dgamma/dt = x15 - x17 reads gamma and its delay slot only -- no control, no
     // theta -- so the gamma path is the SAME for every candidate and needs nothing but the state.  One
@@ -418,7 +448,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // (compiled-in model, wide workgroup: the gamma wave has nothing to fetch)
     const int ltid = wideB ? (tid < nintB ? tid : tid - 64) : tid, LNT = wideB ? NT - 64 : NT;
     if (!(wideB && gwave)) {
-        const T *src = a.U + (size_t)k0 * N * 3;
+        const T *src = Ub + (size_t)k0 * N * 3;
         const int tot = nvalid * N * 3;
         constexpr int VW = 16 / sizeof(T);           // elements per 16-byte lane load
         const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (tot % VW == 0);
@@ -1021,7 +1051,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 
     RV_STAMP(5);
     // ---- phase 5: J_k, block arg-min, outputs ---------------------------------------------
-    const bool fast_tail = a.result && !a.traj_all && N + 1 <= 64;
+    // per-problem views of the outputs (computed here, not at the top: nothing before this point needs them live)
+    T *Jb = a.J + (size_t)prob * K;
+    T *trajb = a.traj_all ? a.traj_all + (size_t)prob * K * (N + 1) * 2 : nullptr;
+    double *blk_trajb = a.blk_traj + (size_t)prob * a.nblocks * (N + 1) * 2;
+    unsigned long long *granb = a.granules + (size_t)prob * 3 * a.nblocks;
+    double *resultb = a.result ? a.result + (size_t)prob * (5 + 2 * (N + 1)) : nullptr;
+    const bool fast_tail = resultb && !a.traj_all && N + 1 <= 64;
     double &s_best_J = *reinterpret_cast<double *>(reinterpret_cast<char *>(smem) + 16);   // header bytes 16..23
     if (tid < 64) {
         const int c = tid;
@@ -1040,7 +1076,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 for (int e = 0; e < 10; ++e) J = J + (n0 + e < N ? v[e] : T(0));
             }
             if (J != J) J = m_inf<T>();                  // NaN cost never wins the arg-min
-            a.J[k0 + c] = J;
+            Jb[k0 + c] = J;
             Jd = (double)J; kk = k0 + c;
         }
         // wave arg-min, lowest index on ties (np.argmin): DPP row shifts when the candidates fit one
@@ -1063,13 +1099,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // the common case: this wave alone hands the workgroup's best over (lane 0 holds it after the reduction):
             // trajectory stores (write-through), drain, then the three tagged granules
             const int cb = __builtin_amdgcn_readfirstlane((int)(kk - k0));
-            double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
+            double *bt = blk_trajb + (size_t)blockIdx.x * (N + 1) * 2;
             if (c <= N) {
                 st_agent(&bt[2 * c], (double)RV_PL(sY, 0, c, cb));
                 st_agent(&bt[2 * c + 1], (double)RV_PL(sY, 1, c, cb));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (c == 0) publish_best(a.granules, a.nblocks, a.epoch, Jd, (unsigned)cb);
+            if (c == 0) publish_best(granb, a.nblocks, a.epoch, Jd, (unsigned)cb);
         } else if (c == 0) {
             s_best_J = Jd;
         }
@@ -1079,21 +1115,21 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(15);
     if (!fast_tail) {
         const int cb = *s_best_c;
-        double *bt = a.blk_traj + (size_t)blockIdx.x * (N + 1) * 2;
+        double *bt = blk_trajb + (size_t)blockIdx.x * (N + 1) * 2;
         for (int i = tid; i < (N + 1); i += NT) {
             st_agent(&bt[2 * i], (double)RV_PL(sY, 0, i, cb));
             st_agent(&bt[2 * i + 1], (double)RV_PL(sY, 1, i, cb));
         }
-        if (a.traj_all) {
+        if (trajb) {
             for (int i = tid; i < nvalid * (N + 1); i += NT) {
                 const int c = i / (N + 1), n = i % (N + 1);
-                T *dst = a.traj_all + ((size_t)(k0 + c) * (N + 1) + n) * 2;
+                T *dst = trajb + ((size_t)(k0 + c) * (N + 1) + n) * 2;
                 dst[0] = RV_PL(sY, 0, n, c); dst[1] = RV_PL(sY, 1, n, c);
             }
         }
     }
     RV_STAMP(6);
-    if (!a.result) return;
+    if (!resultb) return;
     if (!fast_tail) {
 
     // ---- arg-min epilogue in the sweeping workgroup ------------------------------------------------
@@ -1103,13 +1139,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // until all carry the epoch.  No assumption on dispatch order, timing or XCD placement.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) publish_best(a.granules, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c);
+    if (tid == 0) publish_best(granb, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c);
     }
     RV_STAMP(7);
     if ((int)blockIdx.x != a.sweeper) return;
-    argmin_epilogue<T>(a.granules, a.epoch, a.blk_traj, a.nblocks, a.U, N, CK, NT, a.result, a.k_offset,
-                       a.slots, a.rank, a.world, reinterpret_cast<double *>(smem + 4), a.plant_next, a.plant_state, a.plant_feedback,
-                       a.flag_consumed, a.consumed_need, a.flag_rolled, a.rolled_seq);
+    argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
 }
 
 template <typename T, int MODEL, int VT>
@@ -1122,7 +1156,7 @@ rollout_kernel(const RolloutArgs<T> a) {
 // (cost, global index) minimum and decode it.
 __global__ void __launch_bounds__(64)
 select_kernel(const long long *slots, int world, int R, double *result, unsigned long long *flag_consumed = nullptr,
-              unsigned long long consumed_seq = 0) {
+              unsigned long long consumed_seq = 0, const unsigned long long *slot_bad = nullptr, int inject = 0) {
     __shared__ int s_r;
     if (threadIdx.x == 0) {
         double Jd = __builtin_inf(); double kd = __builtin_inf(); int rb = 0;
@@ -1135,23 +1169,30 @@ select_kernel(const long long *slots, int world, int R, double *result, unsigned
     }
     __syncthreads();
     const int rb = s_r;
-    for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = ordered_val(slots[(size_t)rb * R + i]);
-    if (flag_consumed) {                     // every read of the slot buffer is done: it may be rewritten
+    // a hand-off of this use timed out (the row is not this step's): the record says so with a NaN cost
+    const bool bad = slot_bad && ld_agent(slot_bad) == consumed_seq;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = (bad && i == 0) ? __builtin_nan("") : ordered_val(slots[(size_t)rb * R + i]);
+    if (flag_consumed && !(inject & 2)) {    // every read of the slot buffer is done: it may be rewritten
         __syncthreads();
         if (threadIdx.x == 0) st_agent(flag_consumed, consumed_seq);
     }
 }
 
 // Collective stream, ahead of the all-reduce of one step: wait until the rollout kernel of that step (running on the
-// caller's stream) has published its row.  One lane polling with agent-scope loads; gives up after ~10 s.
+// caller's stream) has published its row.  One lane polling with agent-scope loads; on giving up it raises the handle's
+// error word and marks the use bad, so the step's record carries a NaN cost and rovmpc_comm_sync returns an error.
 __global__ void __launch_bounds__(64)
-wait_rolled_kernel(const unsigned long long *flag_rolled, unsigned long long seq, int *timed_out) {
+wait_rolled_kernel(const unsigned long long *flag_rolled, unsigned long long seq, unsigned *err, unsigned long long *slot_bad,
+                   unsigned long long handoff_ticks) {
     if (threadIdx.x != 0) return;
-    for (long spin = 0; spin < (1L << 23); ++spin) {
+    const unsigned long long give_up = wall_clock64() + handoff_ticks;
+    for (;;) {
         if (ld_agent(flag_rolled) >= seq) return;
+        if (wall_clock64() > give_up) break;
         __builtin_amdgcn_s_sleep(16);
     }
-    *timed_out = 1;
+    raise_error(err, ERR_WAIT_ROLLED);
+    st_agent(slot_bad, seq);
 }
 
 // Plant update of the closed-loop driver (one tiny workgroup): exogenous slots from the measured

@@ -53,7 +53,16 @@ struct rovmpc_handle {
     const unsigned long long *arg_flag_consumed = nullptr;   // hand-off flags of the step being enqueued (native collective)
     unsigned long long *arg_flag_rolled = nullptr;
     unsigned long long arg_consumed_need = 0, arg_rolled_seq = 0;
-    int *d_wait_timeout = nullptr;
+    unsigned long long *arg_slot_bad = nullptr;
+    int arg_inject = 0;
+    // error word: pinned host memory mapped into the device (ERR_* bits of rollout_kernels.h), raised at system scope by
+    // the kernels' give-up paths, read and cleared by rovmpc_comm_sync / rovmpc_device_status
+    unsigned *h_err = nullptr, *d_err = nullptr;
+    double handoff_timeout_ms = 10000.0;      // give-up time of the GPU-side hand-off waits (rovmpc_set_option)
+    int inject_skip_rolled = 0, inject_skip_consumed = 0;   // test hooks: the next N steps lose that publication
+    // batched launches: workspace for `batch_cap` problems
+    int batch_cap = 0;
+    void *d_Jb = nullptr; double *d_blk_trajb = nullptr; unsigned long long *d_granulesb = nullptr;
     const double *plant_next = nullptr;       // closed loop: plant update fused into the step being enqueued
     double *plant_state = nullptr;
     int plant_feedback = 0;
@@ -74,14 +83,14 @@ struct rovmpc_handle {
     // GPU-side hand-off between the caller's stream and the collective streams (no events on the caller's stream:
     // an event record costs ~3 us and a cross-stream wait ~6 us of its timeline per step, measured):
     // rolled[p] = uses of slot p whose rollout has published its row; consumed[p] = uses whose select has read it.
-    unsigned long long *d_flags = nullptr;             // [2][NSLOT]
+    unsigned long long *d_flags = nullptr;             // [3][NSLOT]: rolled, consumed, bad use
     unsigned long long slot_uses[NSLOT] = {};
     long long *d_slots[NSLOT] = {};
     hipEvent_t ev_selected[NSLOT] = {};   // recorded at rovmpc_comm_join, one per collective stream
     bool slot_used[NSLOT] = {};
     // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
     // host time per call) overlaps the enqueue of the next rollout
-    struct CommJob { int p; double *d_result; unsigned long long use; int c; };
+    struct CommJob { int p; double *d_result; unsigned long long use; int c; int inject; };
     unsigned long long comm_rr = 0;       // steps issued: communicator of a step = comm_rr % ncomm (same on every rank)
     std::thread comm_thread;
     std::mutex comm_mu;
@@ -177,9 +186,9 @@ static int builtin_kernel_regs(const rovmpc_handle *h) {
 // invariant gamma wave is paid once per workgroup).  CK stays >= 16: fewer leaves theta-wave lanes
 // idle.  tools/geometry_sweep.py measures the whole grid; this rule picks its minimum at
 // (N 20, f64), (N 20, f32), (N 50, f32) and (N 50, f64) for K = 8192 .. 32768.
-static bool throughput_geometry(const rovmpc_handle *h, int n_cu, int *ck_out, int *nt_out) {
+static bool throughput_geometry(const rovmpc_handle *h, int n_cu, long long candidates_in_flight, int *ck_out, int *nt_out) {
     const rovmpc_config *c = &h->cfg;
-    if ((c->K + 15) / 16 <= n_cu) return false;
+    if ((candidates_in_flight + 15) / 16 <= n_cu) return false;
     int alloc = (builtin_kernel_regs(h) + 7) / 8 * 8;
     int S = 512 / alloc; if (S > 8) S = 8; if (S < 1) S = 1;
     long best_w = -1, best_c = -1; int best_ck = 0, best_nt = 0;
@@ -221,7 +230,7 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
     }
     if (strict && model == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
         int ck = 0, nt = 0;
-        if (throughput_geometry(h, h->n_cu, &ck, &nt)) { h->CK = ck; h->NT = nt; }
+        if (throughput_geometry(h, h->n_cu, cfg->K, &ck, &nt)) { h->CK = ck; h->NT = nt; }
     }
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     if (cfg->threads_per_block > 0) h->NT = cfg->threads_per_block;
@@ -231,6 +240,24 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
     return nullptr;
 }
 
+
+// Geometry of one launch: B problems of K candidates each in the grid (B = 1: the handle's own geometry).
+struct Geo { int CK, NT, nblocks; };
+static Geo launch_geometry(const rovmpc_handle *h, int B) {
+    Geo g{h->CK, h->NT, h->nblocks};
+    const rovmpc_config *cfg = &h->cfg;
+    if (B > 1 && h->model_kind == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
+        // what counts is the number of candidates in the grid, whichever problem they belong to
+        int ck = 0, nt = 0;
+        if (throughput_geometry(h, h->n_cu, (long long)B * cfg->K, &ck, &nt)) {
+            while (ck > 16 && ck > cfg->K) ck /= 2;              // never wider than a problem
+            g.CK = ck; g.NT = nt;
+            if (g.NT < 64 * ((g.CK + 15) / 16)) g.NT = 64 * ((g.CK + 15) / 16);
+            g.nblocks = (cfg->K + g.CK - 1) / g.CK;
+        }
+    }
+    return g;
+}
 
 extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *nullh = nullptr;
@@ -302,6 +329,9 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_granules, (size_t)3 * max_blocks * sizeof(unsigned long long)));
     CR(hipMemset(h->d_granules, 0, (size_t)3 * max_blocks * sizeof(unsigned long long)));
     h->epoch_ctr = new unsigned(0);
+    CR(hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped));
+    *h->h_err = 0;
+    CR(hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0));
 #ifdef ROVMPC_STAMPS
     CR(hipMalloc((void **)&h->d_stamps, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
     CR(hipMemset(h->d_stamps, 0, (size_t)max_blocks * 16 * sizeof(unsigned long long)));
@@ -321,7 +351,8 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
-                    h->d_granules};
+                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb};
+    if (h->h_err) (void)hipHostFree(h->h_err);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h->epoch_ctr;
     if (h->h_result) (void)hipHostFree(h->h_result);
@@ -457,42 +488,6 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
 
 // ---- model ---------------------------------------------------------------------------------
 
-// Host-side evaluation of a bytecode program; used ONLY to fingerprint a loaded model against
-// the compiled-in default equations (never to produce results).
-static double host_eval(const int32_t *code, int n, const double *consts, const double *x) {
-    double st[ROVMPC_MAX_STACK + 1];
-    int sp = 0;
-    for (int pc = 0; pc < n; ++pc) {
-        int op = code[pc] & 0xff, arg = code[pc] >> 8;
-        switch (op) {
-        case ROVMPC_OP_PUSH_C: st[sp++] = consts[arg]; break;
-        case ROVMPC_OP_PUSH_F: st[sp++] = x[arg]; break;
-        case ROVMPC_OP_ADD: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
-        case ROVMPC_OP_SUB: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
-        case ROVMPC_OP_MUL: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
-        case ROVMPC_OP_DIV: st[sp - 2] = st[sp - 2] / st[sp - 1]; --sp; break;
-        case ROVMPC_OP_POW: st[sp - 2] = pow(st[sp - 2], st[sp - 1]); --sp; break;
-        case ROVMPC_OP_NEG: st[sp - 1] = -st[sp - 1]; break;
-        case ROVMPC_OP_SIN: st[sp - 1] = sin(st[sp - 1]); break;
-        case ROVMPC_OP_COS: st[sp - 1] = cos(st[sp - 1]); break;
-        case ROVMPC_OP_TANH: st[sp - 1] = tanh(st[sp - 1]); break;
-        case ROVMPC_OP_ABS: st[sp - 1] = fabs(st[sp - 1]); break;
-        case ROVMPC_OP_SQUARE: st[sp - 1] = st[sp - 1] * st[sp - 1]; break;
-        case ROVMPC_OP_EXP: st[sp - 1] = exp(st[sp - 1]); break;
-        case ROVMPC_OP_LOG: st[sp - 1] = log(st[sp - 1]); break;
-        case ROVMPC_OP_SQRT: st[sp - 1] = sqrt(st[sp - 1]); break;
-        case ROVMPC_OP_POWI: {
-            int e = arg >= (1 << 23) ? arg - (1 << 24) : arg;
-            st[sp - 1] = pow(st[sp - 1], (double)e); break;
-        }
-        case ROVMPC_OP_SAFE_LOG: st[sp - 1] = log(fabs(st[sp - 1]) + 1e-5); break;
-        case ROVMPC_OP_SAFE_SQRT: st[sp - 1] = sqrt(fabs(st[sp - 1])); break;
-        default: return NAN;
-        }
-    }
-    return sp == 1 ? st[0] : NAN;
-}
-
 // Static validation: opcodes known, indices in range, stack discipline, final depth 1.
 static const char *validate_code(const int32_t *code, int n, int n_feat, int n_consts) {
     if (n < 1 || n > ROVMPC_MAX_CODE) return "program length out of range";
@@ -513,6 +508,62 @@ static const char *validate_code(const int32_t *code, int n, int n_feat, int n_c
         if (sp > ROVMPC_MAX_STACK) return "expression needs more than ROVMPC_MAX_STACK operands";
     }
     return sp == 1 ? nullptr : "program does not leave exactly one value";
+}
+
+// Structural recognition of the reference's chosen rows.  The bytecode is evaluated over the algebra of affine forms
+// sum_i c_i * atom_i with atoms {1, x_j, sin(x_j)}: constants and features push one-term forms, + - combine terms, * and /
+// need a pure constant on one side (the right side for /), sin needs its argument to be exactly one feature.  Any other
+// operator, or a product of two non-constant forms, ends the recognition (the model is then NOT the compiled-in one, whatever
+// it evaluates to).  Two programs with the same term list are the same function on all of R^18, so this decides identity
+// exactly -- no sample points, no tolerance on values; the coefficients must be the published 0.048152514 to the last bit
+// (the CSV's `equation` form and its expanded `sympy_format` form both give exactly that).
+typedef std::map<int, double> AffineForm;            // atom id -> coefficient; id 0 = 1, 1 + j = x_j, 100 + j = sin(x_j)
+static bool affine_of(const int32_t *code, int n, const double *consts, AffineForm &out) {
+    std::vector<AffineForm> st;
+    auto is_const = [](const AffineForm &f) { for (auto &t : f) if (t.first != 0 && t.second != 0.0) return false; return true; };
+    auto const_of = [](const AffineForm &f) { auto it = f.find(0); return it == f.end() ? 0.0 : it->second; };
+    for (int pc = 0; pc < n; ++pc) {
+        const int op = code[pc] & 0xff, arg = code[pc] >> 8;
+        if (op == ROVMPC_OP_PUSH_C) { st.push_back({{0, consts[arg]}}); continue; }
+        if (op == ROVMPC_OP_PUSH_F) { st.push_back({{1 + arg, 1.0}}); continue; }
+        if (op == ROVMPC_OP_NEG) { for (auto &t : st.back()) t.second = -t.second; continue; }
+        if (op == ROVMPC_OP_SIN) {
+            AffineForm &f = st.back();
+            int feat = -1; bool ok = true;
+            for (auto &t : f) { if (t.second == 0.0) continue; if (t.first >= 1 && t.first < 100 && t.second == 1.0 && feat < 0) feat = t.first - 1; else ok = false; }
+            if (!ok || feat < 0) return false;
+            f = {{100 + feat, 1.0}};
+            continue;
+        }
+        if (op == ROVMPC_OP_ADD || op == ROVMPC_OP_SUB || op == ROVMPC_OP_MUL || op == ROVMPC_OP_DIV) {
+            AffineForm b = st.back(); st.pop_back();
+            AffineForm &a = st.back();
+            if (op == ROVMPC_OP_ADD || op == ROVMPC_OP_SUB) {
+                for (auto &t : b) a[t.first] += op == ROVMPC_OP_ADD ? t.second : -t.second;
+            } else if (op == ROVMPC_OP_MUL) {
+                if (is_const(b)) { const double c = const_of(b); for (auto &t : a) t.second *= c; }
+                else if (is_const(a)) { const double c = const_of(a); a = b; for (auto &t : a) t.second *= c; }
+                else return false;
+            } else {
+                if (!is_const(b)) return false;
+                const double c = const_of(b); for (auto &t : a) t.second /= c;
+            }
+            continue;
+        }
+        return false;
+    }
+    if (st.size() != 1) return false;
+    out.clear();
+    for (auto &t : st[0]) if (t.second != 0.0) out[t.first] = t.second;
+    return true;
+}
+static bool is_reference_rows(const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga, const double *consts) {
+    AffineForm th, ga;
+    if (!affine_of(code_th, n_th, consts, th) || !affine_of(code_ga, n_ga, consts, ga)) return false;
+    const double KT = 0.048152514;
+    const AffineForm want_th = {{1 + 16, -KT}, {1 + 3, -KT}, {100 + 17, KT}, {100 + 3, -KT}};
+    const AffineForm want_ga = {{1 + 15, 1.0}, {1 + 17, -1.0}};
+    return th == want_th && ga == want_ga;
 }
 
 extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const double *mean, const double *scale,
@@ -553,24 +604,12 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
         fill_consts<float>(h, k);
         HIPCHK(h, hipMemcpy(h->d_k, &k, sizeof(k), hipMemcpyHostToDevice));
     }
-    // Fingerprint against the compiled-in rows of saved_models/equations_*.csv
-    // (complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3: x15 - x17).
-    bool same = n_features == 18 && !h->cfg.force_interpreter && h->cfg.feature_map == ROVMPC_FEATURES_GEN1;
-    if (same) {
-        unsigned long long s = 0x9E3779B97F4A7C15ULL;
-        for (int t = 0; t < 16 && same; ++t) {
-            double x[18];
-            for (int i = 0; i < 18; ++i) {
-                s = s * 6364136223846793005ULL + 1442695040888963407ULL;
-                x[i] = ((double)(s >> 11) / 9007199254740992.0) * 6.0 - 3.0;
-            }
-            const double rt = (((sin(x[17]) - sin(x[3])) - x[16]) - x[3]) * 0.048152514;
-            const double rg = x[15] - x[17];
-            const double gt = host_eval(code_theta, n_code_theta, consts, x);
-            const double gg = host_eval(code_gamma, n_code_gamma, consts, x);
-            same = fabs(gt - rt) <= 1e-12 * (1.0 + fabs(rt)) && fabs(gg - rg) <= 1e-12 * (1.0 + fabs(rg));
-        }
-    }
+    // The compiled-in kernel is substituted only for a model that IS the reference's chosen rows
+    // (saved_models/equations_*.csv complexity 13: ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514); complexity 3:
+    // x15 - x17), decided structurally -- see is_reference_rows -- never by sampling the functions.
+    const bool same = n_features == 18 && !h->cfg.force_interpreter && !h->cfg.no_builtin &&
+                      h->cfg.feature_map == ROVMPC_FEATURES_GEN1 &&
+                      is_reference_rows(code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
     {
         // exogenous planes the expressions read (plane 13 = angle_proj: feature 13, or 16 in generation 2)
         unsigned m = 0;
@@ -622,32 +661,35 @@ extern "C" int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R) {
 // ---- launches -------------------------------------------------------------------------------
 
 template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<T> &a, const double *d_state,
-                                            const void *d_U, void *d_traj_all) {
+                                            const void *d_U, void *d_traj_all, const Geo &g, int B) {
     const rovmpc_config &c = h->cfg;
     a.U = (const T *)d_U; a.state = d_state; a.k = (const RolloutConsts<T> *)h->d_k;
     a.code_th = h->d_code_th; a.code_ga = h->d_code_ga;
     a.consts = (const T *)h->d_consts; a.Rtab = (const T *)h->d_Rtab;
     a.J = (T *)h->d_J; a.traj_all = (T *)d_traj_all;
     a.blk_traj = h->d_blk_traj;
-    a.N = c.N; a.K = c.K; a.CK = h->CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
+    a.N = c.N; a.K = c.K; a.CK = g.CK; a.M = c.n_shape_pts; a.n_th = h->n_th; a.n_ga = h->n_ga;
     a.prev_mode = c.prev_mode; a.integrator = c.integrator; a.debug = c.debug_flags; a.fmap = c.feature_map;
     a.used_planes = h->used_planes;
     a.ck_shift = 0;
-    while ((1 << a.ck_shift) < h->CK) ++a.ck_shift;
+    while ((1 << a.ck_shift) < g.CK) ++a.ck_shift;
     a.magic_3n = (unsigned)(4294967296ULL / (unsigned long long)(3 * c.N)) + 1u;
-    a.granules = h->d_granules;
-    a.sweeper = h->nblocks <= h->n_cu ? 0 : h->nblocks - 1;
+    a.granules = B > 1 ? h->d_granulesb : h->d_granules;
+    if (B > 1) { a.J = (T *)h->d_Jb; a.blk_traj = h->d_blk_trajb; }
+    a.sweeper = (long long)B * g.nblocks <= h->n_cu ? 0 : g.nblocks - 1;
     if (++*h->epoch_ctr == 0) ++*h->epoch_ctr;      // never 0 (the granules start zeroed)
     a.epoch = *h->epoch_ctr;
-    a.NT = h->NT; a.nblocks = h->nblocks;
+    a.NT = g.NT; a.nblocks = g.nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
     a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
     a.consumed_need = h->arg_consumed_need; a.rolled_seq = h->arg_rolled_seq;
+    a.slot_bad = h->arg_slot_bad; a.err = h->d_err; a.inject = h->arg_inject;
+    a.handoff_ticks = (unsigned long long)(h->handoff_timeout_ms * 1e5);      // 100 MHz clock
     a.stamps = h->d_stamps;
 }
 
 template <typename T, int MODEL, int VT>
-static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, hipStream_t s) {
+static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, int B, hipStream_t s) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL, VT) * sizeof(T);
     auto kern = rollout_kernel<T, MODEL, VT>;
     if (lds > 64 * 1024) {
@@ -659,37 +701,38 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, hi
     if (!told && getenv("ROVMPC_DIAG_OCCUPANCY")) {
         told = true;
         int nb = -1; hipFuncAttributes fa{};
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, h->NT, lds);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, a.NT, lds);
         hipFuncGetAttributes(&fa, (const void *)kern);
         fprintf(stderr, "[rovmpc diag] NT %d lds %zu: resident workgroups/CU %d; regs %d static lds %zu scratch %zu maxThreads %d\n",
-                h->NT, lds, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
+                a.NT, lds, nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxThreadsPerBlock);
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(h->nblocks), dim3(h->NT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.nblocks, B), dim3(a.NT), lds, s, a);
     return hipGetLastError();
 }
 
 template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h, const double *d_state, const void *d_U,
                                                          void *d_traj_all, double *d_result, long long k_offset,
-                                                         long long *d_slots, int rank, int world, hipStream_t s) {
+                                                         long long *d_slots, int rank, int world, hipStream_t s, int B = 1) {
     RolloutArgs<T> a;
-    fill_args<T>(h, a, d_state, d_U, d_traj_all);
+    const Geo g = launch_geometry(h, B);
+    fill_args<T>(h, a, d_state, d_U, d_traj_all, g, B);
     a.result = d_result; a.k_offset = k_offset; a.slots = d_slots; a.rank = rank; a.world = world;
     const int vt = h->cfg.vt_mode;
     if (h->model_kind == MODEL_JIT) {
         const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt) * sizeof(T);
         size_t asz = sizeof(a);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-        return hipModuleLaunchKernel(h->jit_fn, h->nblocks, 1, 1, h->NT, 1, 1, (unsigned)lds, s, nullptr, extra);
+        return hipModuleLaunchKernel(h->jit_fn, a.nblocks, B, 1, a.NT, 1, 1, (unsigned)lds, s, nullptr, extra);
     }
     if (h->builtin) {
-        if (vt == 0) return launch_one<T, MODEL_BUILTIN, 0>(h, a, s);
-        if (vt == 1) return launch_one<T, MODEL_BUILTIN, 1>(h, a, s);
-        return launch_one<T, MODEL_BUILTIN, 2>(h, a, s);
+        if (vt == 0) return launch_one<T, MODEL_BUILTIN, 0>(h, a, B, s);
+        if (vt == 1) return launch_one<T, MODEL_BUILTIN, 1>(h, a, B, s);
+        return launch_one<T, MODEL_BUILTIN, 2>(h, a, B, s);
     }
-    if (vt == 0) return launch_one<T, MODEL_INTERP, 0>(h, a, s);
-    if (vt == 1) return launch_one<T, MODEL_INTERP, 1>(h, a, s);
-    return launch_one<T, MODEL_INTERP, 2>(h, a, s);
+    if (vt == 0) return launch_one<T, MODEL_INTERP, 0>(h, a, B, s);
+    if (vt == 1) return launch_one<T, MODEL_INTERP, 1>(h, a, B, s);
+    return launch_one<T, MODEL_INTERP, 2>(h, a, B, s);
 }
 
 static int check_ready(rovmpc_handle *h) {
@@ -703,14 +746,14 @@ static int check_ready(rovmpc_handle *h) {
 }
 
 static int enqueue_step(rovmpc_handle *h, const double *d_state, const void *d_U, void *d_traj_all, double *d_result,
-                        long long k_offset, long long *d_slots, int rank, int world, hipStream_t s) {
+                        long long k_offset, long long *d_slots, int rank, int world, hipStream_t s, int B = 1) {
     int rc = check_ready(h);
     if (rc) return rc;
     const bool time_it = h->timing && h->ev_used + 2 <= (int)h->ev.size();
     if (time_it) HIPCHK(h, hipEventRecord(h->ev[h->ev_used], s));
     hipError_t e = h->cfg.dtype == ROVMPC_F64
-                       ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s)
-                       : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s);
+                       ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s, B)
+                       : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s, B);
     if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
     if (time_it) { HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
     return ROVMPC_OK;
@@ -720,6 +763,74 @@ extern "C" int rovmpc_step_device(rovmpc_handle *h, const double *d_state, const
     if (!h) return ROVMPC_ERR_INVALID;
     if (!d_state || !d_U || !d_result) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device: null pointer");
     return enqueue_step(h, d_state, d_U, nullptr, d_result, 0, nullptr, 0, 1, (hipStream_t)stream);
+}
+
+// Workspace of a batched launch: costs, per-workgroup trajectories and hand-off granules for B problems.
+static int ensure_batch(rovmpc_handle *h, int B) {
+    if (B <= h->batch_cap) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());               // nothing may still be using the old buffers
+    void *old[] = {h->d_Jb, h->d_blk_trajb, h->d_granulesb};
+    for (void *p : old) if (p) (void)hipFree(p);
+    h->d_Jb = nullptr; h->d_blk_trajb = nullptr; h->d_granulesb = nullptr; h->batch_cap = 0;
+    const rovmpc_config &c = h->cfg;
+    const size_t max_blocks = c.candidates_per_block > 0 ? (size_t)((c.K + c.candidates_per_block - 1) / c.candidates_per_block) : (size_t)c.K;
+    HIPCHK(h, hipMalloc(&h->d_Jb, (size_t)B * c.K * h->esz));
+    HIPCHK(h, hipMalloc((void **)&h->d_blk_trajb, (size_t)B * max_blocks * (c.N + 1) * 2 * sizeof(double)));
+    HIPCHK(h, hipMalloc((void **)&h->d_granulesb, (size_t)B * 3 * max_blocks * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_granulesb, 0, (size_t)B * 3 * max_blocks * sizeof(unsigned long long)));
+    h->batch_cap = B;
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_step_batch_device(rovmpc_handle *h, int32_t B, const double *d_states, const void *d_U, double *d_results,
+                                        void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (B < 1 || B > 65535) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_batch_device: B must be in 1..65535 (got %d)", B);
+    if (!d_states || !d_U || !d_results) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_batch_device: null pointer");
+    if (B == 1) return enqueue_step(h, d_states, d_U, nullptr, d_results, 0, nullptr, 0, 1, (hipStream_t)stream);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    return enqueue_step(h, d_states, d_U, nullptr, d_results, 0, nullptr, 0, 1, (hipStream_t)stream, B);
+}
+
+extern "C" int rovmpc_batch_costs_device(rovmpc_handle *h, const void **d_J) {
+    if (!h || !d_J) return ROVMPC_ERR_INVALID;
+    *d_J = h->batch_cap > 0 ? h->d_Jb : h->d_J;
+    return ROVMPC_OK;
+}
+
+// Error word of the handle (non-blocking): 0 = nothing raised; otherwise ROVMPC_ERR_HIP with the reason, and the word is
+// cleared.  Only meaningful for work the host has already synchronised with.
+static int take_device_errors(rovmpc_handle *h) {
+    if (!h->h_err) return ROVMPC_OK;
+    const unsigned e = __atomic_exchange_n(h->h_err, 0u, __ATOMIC_ACQ_REL);
+    if (!e) return ROVMPC_OK;
+    FAIL(h, ROVMPC_ERR_HIP, "GPU-side hand-off gave up:%s%s%s -- the affected step's record carries a NaN cost",
+         (e & ERR_WAIT_ROLLED) ? " [a collective never saw its rollout's row]" : "",
+         (e & ERR_CONSUMED) ? " [a rollout never saw the select that frees its slot row]" : "",
+         (e & ERR_SWEEP) ? " [the arg-min sweep never saw a workgroup's record]" : "");
+}
+
+extern "C" int rovmpc_device_status(rovmpc_handle *h) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    return take_device_errors(h);
+}
+
+extern "C" int rovmpc_set_option(rovmpc_handle *h, const char *name, double value) {
+    if (!h || !name) return ROVMPC_ERR_INVALID;
+    if (!strcmp(name, "handoff_timeout_ms")) {
+        if (!(value > 0) || value > 600000.0) FAIL(h, ROVMPC_ERR_INVALID, "handoff_timeout_ms must be in (0, 600000]");
+        h->handoff_timeout_ms = value;
+    } else if (!strcmp(name, "inject_skip_rolled")) {
+        h->inject_skip_rolled = (int)value;
+    } else if (!strcmp(name, "inject_skip_consumed")) {
+        h->inject_skip_consumed = (int)value;
+    } else {
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_set_option: unknown option '%s'", name);
+    }
+    return ROVMPC_OK;
 }
 
 extern "C" int rovmpc_step_device_sharded(rovmpc_handle *h, const double *d_state, const void *d_U, int64_t k_offset,
@@ -1220,10 +1331,12 @@ static void comm_worker(rovmpc_handle *h) {
         const int p = job.p;
         ncclComm_t comm = h->comms[job.c];
         hipStream_t cs = h->comm_streams[job.c];
-        unsigned long long *f_rolled = h->d_flags + p, *f_consumed = h->d_flags + rovmpc_handle::NSLOT + p;
+        unsigned long long *f_rolled = h->d_flags + p, *f_consumed = h->d_flags + rovmpc_handle::NSLOT + p,
+                           *f_bad = h->d_flags + 2 * rovmpc_handle::NSLOT + p;
+        const unsigned long long ticks = (unsigned long long)(h->handoff_timeout_ms * 1e5);
         std::string err;
         // the rollout of this use publishes its row with a sequence number; no event on the caller's stream
-        hipLaunchKernelGGL(wait_rolled_kernel, dim3(1), dim3(64), 0, cs, (const unsigned long long *)f_rolled, job.use, h->d_wait_timeout);
+        hipLaunchKernelGGL(wait_rolled_kernel, dim3(1), dim3(64), 0, cs, (const unsigned long long *)f_rolled, job.use, h->d_err, f_bad, ticks);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) err = std::string("wait kernel: ") + hipGetErrorString(e);
         if (err.empty()) {
@@ -1232,7 +1345,7 @@ static void comm_worker(rovmpc_handle *h) {
         }
         if (err.empty()) {
             hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, cs, (const long long *)h->d_slots[p],
-                               h->comm_world, (int)R, job.d_result, f_consumed, job.use);
+                               h->comm_world, (int)R, job.d_result, f_consumed, job.use, (const unsigned long long *)f_bad, job.inject);
             e = hipGetLastError();
             if (e != hipSuccess) err = std::string("select kernel: ") + hipGetErrorString(e);
         }
@@ -1271,10 +1384,8 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     int lo = 0, hi = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(h, hipStreamCreateWithPriority(&h->comm_streams[0], hipStreamNonBlocking, hi));
-    HIPCHK(h, hipMalloc((void **)&h->d_flags, 2 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(h->d_flags, 0, 2 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
-    HIPCHK(h, hipMalloc((void **)&h->d_wait_timeout, sizeof(int)));
-    HIPCHK(h, hipMemset(h->d_wait_timeout, 0, sizeof(int)));
+    HIPCHK(h, hipMalloc((void **)&h->d_flags, 3 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_flags, 0, 3 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
     {
         // More communicators (ROVMPC_COMMS=1 keeps the single one).  Rank 0 draws their ids and hands them round
         // with ncclBroadcast on the first communicator; every rank then agrees (one all-reduce(min) of a flag) that
@@ -1351,12 +1462,17 @@ extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_st
     const unsigned long long use = ++h->slot_uses[p];
     h->arg_flag_consumed = h->d_flags + rovmpc_handle::NSLOT + p; h->arg_consumed_need = use - 1;
     h->arg_flag_rolled = h->d_flags + p; h->arg_rolled_seq = use;
+    h->arg_slot_bad = h->d_flags + 2 * rovmpc_handle::NSLOT + p;
+    int inject = 0;
+    if (h->inject_skip_rolled > 0) { --h->inject_skip_rolled; inject |= 1; }
+    if (h->inject_skip_consumed > 0) { --h->inject_skip_consumed; inject |= 2; }
+    h->arg_inject = inject;
     int rc = enqueue_step(h, d_state, d_U, nullptr, h->d_result, k_offset, h->d_slots[p], h->comm_rank, h->comm_world, s);
-    h->arg_flag_consumed = nullptr; h->arg_flag_rolled = nullptr;
+    h->arg_flag_consumed = nullptr; h->arg_flag_rolled = nullptr; h->arg_slot_bad = nullptr; h->arg_inject = 0;
     if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(h->comm_mu);
-        h->comm_q.push_back({p, d_result, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm)});
+        h->comm_q.push_back({p, d_result, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm), inject});
         ++h->comm_submitted[p];
     }
     h->comm_cv.notify_all();
@@ -1379,7 +1495,17 @@ extern "C" int rovmpc_comm_join(rovmpc_handle *h, void *stream) {
         HIPCHK(h, hipEventRecord(h->ev_selected[c], h->comm_streams[c]));
         HIPCHK(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_selected[c], 0));
     }
-    return ROVMPC_OK;
+    // a hand-off that gave up in a step the GPU has already executed is reported here (the join itself does not block)
+    return take_device_errors(h);
+}
+
+extern "C" int rovmpc_comm_sync(rovmpc_handle *h, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    int rc = rovmpc_comm_join(h, stream);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return take_device_errors(h);
 }
 
 extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
@@ -1397,10 +1523,7 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
         if (h->comms[c]) { (void)g_rccl.CommDestroy(h->comms[c]); h->comms[c] = nullptr; }
     h->comm = nullptr; h->ncomm = 0;
-    int timed_out = 0;
-    if (h->d_wait_timeout) (void)hipMemcpy(&timed_out, h->d_wait_timeout, sizeof(int), hipMemcpyDeviceToHost);
     if (h->d_flags) { (void)hipFree(h->d_flags); h->d_flags = nullptr; }
-    if (h->d_wait_timeout) { (void)hipFree(h->d_wait_timeout); h->d_wait_timeout = nullptr; }
     for (int i = 0; i < rovmpc_handle::NSLOT; ++i) {
         if (h->d_slots[i]) (void)hipFree(h->d_slots[i]);
         if (h->ev_selected[i]) (void)hipEventDestroy(h->ev_selected[i]);
@@ -1408,9 +1531,7 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     }
     for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
         if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
-    if (timed_out)
-        FAIL(h, ROVMPC_ERR_HIP, "a collective gave up waiting for its rollout kernel (~10 s): results of that step are not valid");
-    return ROVMPC_OK;
+    return take_device_errors(h);       // anything raised since the last rovmpc_comm_sync
 }
 
 // ---- closed loop ----------------------------------------------------------------------------------

@@ -32,6 +32,7 @@ class MPCConfig:
     threads_per_block: int = 0
     debug_flags: int = 0
     jit: bool = True             # specialise non-default models with hiprtc at set_model
+    no_builtin: bool = False     # never substitute the compiled-in kernel for the reference's chosen rows
     feature_map: int = _lib.FEATURES_GEN1   # FEATURES_GEN2: 17 unscaled slots of simulate_rk4_theta_gamma.py:12-42
     dt: float = 1.0 / 60.0
     v_scale: float = 1e-3
@@ -68,6 +69,7 @@ class MPCConfig:
         c.threads_per_block = self.threads_per_block
         c.debug_flags = self.debug_flags
         c.jit_off = 0 if self.jit else 1
+        c.no_builtin = int(self.no_builtin)
         c.feature_map = self.feature_map
         for k in ("dt", "v_scale", "L", "cable_wet_weight", "c_lo", "c_hi", "w_theta", "w_gamma", "w_u", "w_T",
                   "w_taut", "rho_taut", "w_floor", "z_floor", "theta_ref", "gamma_ref"):
@@ -253,11 +255,32 @@ class Engine:
     def comm_join(self, stream: int = 0):
         self._check(self.lib.rovmpc_comm_join(self._h, stream))
 
+    def comm_sync(self, stream: int = 0):
+        """Join + synchronise ``stream``; raises ``RovmpcError`` if a GPU-side hand-off of any enqueued step gave up."""
+        self._check(self.lib.rovmpc_comm_sync(self._h, stream))
+
+    def set_option(self, name: str, value: float):
+        self._check(self.lib.rovmpc_set_option(self._h, name.encode(), float(value)))
+
+    def device_status(self):
+        self._check(self.lib.rovmpc_device_status(self._h))
+
+    def step_batch_device(self, B: int, d_states: int, d_U: int, d_results: int, stream: int = 0):
+        """B independent problems in one launch: d_states[B][16], d_U[B][K][N][3], d_results[B][result_len]."""
+        self._check(self.lib.rovmpc_step_batch_device(self._h, B, d_states, d_U, d_results, stream))
+
+    def batch_costs_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.rovmpc_batch_costs_device(self._h, C.byref(p)))
+        return p.value
+
     def comm_destroy(self):
         self._check(self.lib.rovmpc_comm_destroy(self._h))
 
     def closed_loop_device(self, d_exo: int, T: int, d_state: int, d_pools: int, n_pools: int, d_results: int,
-                           k_offset: int = 0, feedback: bool = False, stream: int = 0):
+                           k_offset: int = 0, feedback: bool = False, stream: int = 0, persistent: bool = False):
+        if persistent:
+            raise RovmpcError(-4, "persistent closed loop is not built yet")
         self._check(self.lib.rovmpc_closed_loop_device(self._h, d_exo, T, d_state, d_pools, n_pools, k_offset,
                                                        int(feedback), d_results, stream))
 

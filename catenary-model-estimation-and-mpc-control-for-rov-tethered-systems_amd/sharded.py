@@ -65,7 +65,7 @@ class ShardedMPC:
 
     def __init__(self, engine=None, rank: Optional[int] = None, world: Optional[int] = None,
                  K_total: Optional[int] = None, local_solver: Optional[Callable] = None, group=None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, host_staged: bool = False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -74,6 +74,7 @@ class ShardedMPC:
         self.engine = engine
         self.local_solver = local_solver
         self.force_collective = force_collective      # run the all-reduce even at world == 1 (rehearsal)
+        self.host_staged = host_staged                # gloo rehearsal: the slot image crosses the host (blocking)
         if engine is None and local_solver is None:
             raise ValueError("ShardedMPC needs an Engine (GPU) or a local_solver")
         if engine is not None:
@@ -97,6 +98,17 @@ class ShardedMPC:
         eng = self.engine
         eng.step_device_sharded(d_state.data_ptr(), d_U.data_ptr(), self.k_offset, self.rank, self.world,
                                 self.slots[i].data_ptr(), cur.cuda_stream)
+        if self.host_staged:
+            # rehearsal of the N > 1 step without RCCL (gloo reduces host tensors): same kernels, same slot image,
+            # same select -- only the transport differs, and it blocks
+            cur.synchronize()
+            image = self.slots[i].cpu()
+            if self.world > 1 or self.force_collective:
+                self.dist.all_reduce(image, op=self.dist.ReduceOp.MIN, group=self.group)
+            self.slots[i].copy_(image)
+            eng.select_device(self.slots[i].data_ptr(), self.world, self.results[i].data_ptr(), cur.cuda_stream)
+            self._selected[i].record(cur)
+            return
         self._rolled[i].record(cur)
         comm.wait_event(self._rolled[i])
         with torch.cuda.stream(comm):
@@ -190,9 +202,10 @@ class NativeShardedMPC:
         return self.results[i]
 
     def synchronize(self):
+        """Blocks until every enqueued step's global record is final; raises ``RovmpcError`` when a GPU-side hand-off
+        (rollout -> collective -> select) of any of them gave up -- that step's record then carries a NaN cost."""
         cur = torch.cuda.current_stream()
-        self.engine.comm_join(cur.cuda_stream)
-        cur.synchronize()
+        self.engine.comm_sync(cur.cuda_stream)
 
     def close(self):
         self.engine.comm_destroy()

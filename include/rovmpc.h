@@ -117,6 +117,8 @@ typedef struct rovmpc_config {
     int32_t jit_off;            /* 1: never specialise a loaded model with hiprtc           */
     int32_t feature_map;        /* ROVMPC_FEATURES_GEN1 | _GEN2 | _GEN3                     */
     int32_t threads_per_block;  /* 0 = auto; else a multiple of 64 in 64..512                */
+    int32_t no_builtin;         /* 1: never substitute the compiled-in kernel, even for the reference's chosen rows
+                                   (they then run through hiprtc / the interpreter like any other model)            */
     double dt;                  /* horizon step [s]                                         */
     double v_scale;             /* velocity unit -> m/s (1e-3: mm/s, cf. main_fun.py:815)   */
     double L;                   /* cable length [m] (test_cluster.py:22)                    */
@@ -187,6 +189,24 @@ int32_t rovmpc_result_len(const rovmpc_handle *h);
 int rovmpc_step_device(rovmpc_handle *h, const double *d_state, const void *d_U,
                        double *d_result, void *stream);
 
+/* B independent MPC problems in ONE launch (grid = B x workgroups; every problem has its own sweeper, hand-off granules
+ * and record): d_states[B][16], d_U[B][K][N][3], d_results[B][result_len].  The natural multi-ROV / multi-timestep form
+ * of the reference's per-frame loop over independent states (catenary_from_data.py:40-50), and the way to fill the
+ * chip when one problem (K = 4096) is only one workgroup per CU.  Problem b's record is bit-identical to
+ * rovmpc_step_device on (d_states[b], d_U[b]).  rovmpc_batch_costs_device returns the device pointer of the costs
+ * J[B][K] of the last batched launch (reals of cfg.dtype; valid until the next launch on the handle). */
+int rovmpc_step_batch_device(rovmpc_handle *h, int32_t B, const double *d_states, const void *d_U,
+                             double *d_results, void *stream);
+int rovmpc_batch_costs_device(rovmpc_handle *h, const void **d_J);
+
+/* Handle options by name: "handoff_timeout_ms" (give-up time of the GPU-side waits of the sharded step, default 10000);
+ * test hooks "inject_skip_rolled" / "inject_skip_consumed" = n: the next n sharded steps lose that publication. */
+int rovmpc_set_option(rovmpc_handle *h, const char *name, double value);
+
+/* Non-blocking: ROVMPC_ERR_HIP (and the reason in rovmpc_last_error) if a kernel of this handle raised its error word
+ * (a hand-off wait that gave up) in work the host has already synchronised with; clears the word. */
+int rovmpc_device_status(rovmpc_handle *h);
+
 /* Candidate-sharded step (one handle per rank): writes this rank's record, order-preserving
  * mapped to int64 (k* offset by k_offset), into d_slots[world][result_len] with every
  * other rank's row = INT64_MAX, so that ONE all-reduce(min) over the buffer assembles all
@@ -215,7 +235,13 @@ int rovmpc_comm_unique_id(void *id128);
 int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t rank, int32_t world);
 int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const void *d_U,
                                  int64_t k_offset, double *d_result, void *stream);
-int rovmpc_comm_join(rovmpc_handle *h, void *stream);   /* make `stream` wait for the side stream */
+/* rovmpc_comm_join: make `stream` wait for the collective streams (does not block the host); returns ROVMPC_ERR_HIP if a
+ * hand-off of an already executed step gave up.  rovmpc_comm_sync: join + synchronise `stream` + report such give-ups of
+ * every step enqueued so far: a wait that timed out (rollout row never published, slot row never freed) makes that
+ * step's record carry a NaN cost, leaves the slot row untouched, and turns this call into an error -- never a silent
+ * wrong record. */
+int rovmpc_comm_join(rovmpc_handle *h, void *stream);
+int rovmpc_comm_sync(rovmpc_handle *h, void *stream);
 int rovmpc_comm_destroy(rovmpc_handle *h);
 
 /* Closed loop, device resident (BASELINE config 5): for i = 0..T-1 enqueue, without any host

@@ -306,8 +306,8 @@ def test_rollout_other_pareto_rows(rv, orc, ct, cg, jit):
 @pytest.mark.parametrize("vt_mode,prev_mode,integrator,dtype", [(0, 0, 0, "f64"), (2, 1, 0, "f64"), (1, 0, 1, "f64"), (1, 0, 0, "f32")])
 def test_jit_specialisation_modes(rv, orc, vt_mode, prev_mode, integrator, dtype):
     """hiprtc-specialised kernel for a model with the generation-2 operator mix, in the other kernel
-    modes, and that the default rows loaded through the JIT route (compiled-in path disabled by a
-    perturbed constant) agree with the compiled-in kernel."""
+    modes, and that the default rows loaded through the JIT route (compiled-in substitution switched
+    off with cfg.no_builtin) agree with the compiled-in kernel."""
     mean, scale = rv.default_model().mean, rv.default_model().scale
     model = rv.DynamicsModel(mean, scale, "0.05*(sin(x17) - tanh(x3*1.6) - x16) + 0.01*Abs(x11)*x6/(1.0 + x12**2) - 0.002*exp(-x0**2)",
                              "x15 - x17 + 0.008*(x3 - sin(x15)) + 0.001*x13*cos(x9)")
@@ -321,13 +321,14 @@ def test_jit_specialisation_modes(rv, orc, vt_mode, prev_mode, integrator, dtype
     np.testing.assert_allclose(J, Jo, rtol=tol)
     if dtype == "f64":
         assert res.index == int(np.argmin(Jo))
-        m2 = rv.DynamicsModel(mean, scale, rv.default_model().expr_theta + " + 0.0*x0", "x15 - x17")
+        # the reference's own rows through the hiprtc route (no_builtin) against the compiled-in kernel
         cfg2 = rv.MPCConfig(N=20, K=256, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator)
+        cfgj = rv.MPCConfig(N=20, K=256, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator, no_builtin=True)
         state, U = rv.synthetic_problem(256, 20)
-        with rv.Engine(cfg2, m2) as ej, rv.Engine(cfg2) as eb:
+        with rv.Engine(cfgj) as ej, rv.Engine(cfg2) as eb:
             if Rtab is not None:
                 R20 = rand_rtab(20); ej.set_rotation_table(R20); eb.set_rotation_table(R20)
-            assert eb.model_path == "builtin"
+            assert eb.model_path == "builtin" and ej.model_path == "jit"
             np.testing.assert_allclose(ej.rollout_costs(state, U), eb.rollout_costs(state, U), rtol=1e-11)
 
 
@@ -724,6 +725,191 @@ def test_native_rccl_step_single_rank(rv):
             r = rec.cpu().numpy()
             assert r[0] == want[i].cost and int(r[1]) == want[i].index and np.array_equal(r[2:5], want[i].u)
         smpc.close()
+
+
+def test_builtin_substitution_is_structural(rv):
+    """The compiled-in kernel replaces a loaded model only when the model IS the reference's rows (same affine form over
+    {x_j, sin x_j}, coefficients to the last bit) -- in either spelling of the CSV -- never for a model that merely agrees
+    with them on some sample box."""
+    m = rv.default_model()
+    cfg = rv.MPCConfig(N=4, K=16)
+    spellings = ["((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)", m.expr_theta, "0.048152514*(sin(x17) - x3 - sin(x3) - x16) + 0.0*x0"]
+    for expr in spellings:
+        with rv.Engine(cfg, rv.DynamicsModel(m.mean, m.scale, expr, "x15 - x17")) as e:
+            assert e.model_path == "builtin", expr
+    others = [m.expr_theta + " + 1e-30*x0",                                  # differs by a term no sample would notice
+              m.expr_theta.replace("0.048152514*sin(x17)", "0.048152515*sin(x17)"),
+              m.expr_theta + " + 0.0*Abs(x3)",                              # an operator outside the affine algebra
+              "0.048152514*(sin(x17 + 1e-12) - x3 - sin(x3) - x16)"]
+    for expr in others:
+        with rv.Engine(cfg, rv.DynamicsModel(m.mean, m.scale, expr, "x15 - x17")) as e:
+            assert e.model_path == "jit", expr
+    with rv.Engine(cfg, rv.DynamicsModel(m.mean, m.scale, m.expr_theta, "x15 - 1.0000000001*x17")) as e:
+        assert e.model_path == "jit"
+
+
+@pytest.mark.parametrize("B,K,N,dtype", [(8, 4096, 20, "f64"), (3, 67, 7, "f64"), (5, 1024, 20, "f32"), (64, 256, 20, "f64")])
+def test_batched_problems_equal_single_launches(rv, orc, B, K, N, dtype):
+    """rovmpc_step_batch_device: B independent problems (own state, own candidates) in one launch.  Every problem's
+    record and costs are bit-equal to its own single launch; problem 0 and B-1 are checked against the oracle."""
+    import torch
+    cfg = rv.MPCConfig(N=N, K=K, dtype=dtype)
+    dev = torch.device("cuda", 0)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    states = np.empty((B, 16)); U = np.empty((B, K, N, 3), dtype=cfg.np_dtype)
+    for b in range(B):
+        states[b], U[b] = rv.synthetic_problem(K, N, seed=900 + b, dtype=cfg.np_dtype)
+        states[b, 12:14] += 0.01 * b                                   # different (theta, gamma) per problem
+    d_states = torch.tensor(states, device=dev); d_U = torch.tensor(U, device=dev, dtype=tdt)
+    stream = torch.cuda.current_stream().cuda_stream
+    with rv.Engine(cfg) as e:
+        R = e.result_len
+        d_res = torch.full((B, R), float("nan"), dtype=torch.float64, device=dev)
+        e.step_batch_device(B, d_states.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), stream)
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy()
+        import ctypes
+        nbytes = B * K * (8 if dtype == "f64" else 4)
+        Jall = torch.empty((B, K), dtype=tdt, device=dev)
+        # device-to-device copy of the batched cost array (pointer from the ABI)
+        ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(Jall.data_ptr()), ctypes.c_void_p(e.batch_costs_ptr()), ctypes.c_size_t(nbytes), 3)
+        Jall = Jall.cpu().numpy()
+        e.step_batch_device(B, d_states.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), stream)     # and again: epochs advance
+        torch.cuda.synchronize()
+        assert np.array_equal(d_res.cpu().numpy(), res)
+        single = torch.empty(R, dtype=torch.float64, device=dev)
+        for b in range(B):
+            e.step_device(d_states[b].data_ptr(), d_U[b].data_ptr(), single.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(single.cpu().numpy(), res[b]), b
+            if b in (0, B - 1):
+                J1 = e.rollout_costs(states[b], U[b])
+                assert np.array_equal(J1, Jall[b])
+    model = rv.default_model()
+    for b in (0, B - 1):
+        Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(states[b]), U[b].astype(np.float64))
+        k = int(np.argmin(Jo))
+        if dtype == "f64":
+            assert int(res[b, 1]) == k
+            np.testing.assert_allclose(res[b, 0], Jo[k], rtol=1e-9)
+            np.testing.assert_allclose(res[b, 5:].reshape(-1, 2), trajo[k], rtol=1e-9, atol=1e-12)
+            assert np.array_equal(res[b, 2:5], U[b, k, 0])
+        else:
+            assert int(res[b, 1]) == k or abs(Jo[int(res[b, 1])] - Jo[k]) / Jo[k] < 1e-4
+
+
+def test_batched_launch_with_other_models(rv, orc):
+    """The batched grid through the hiprtc and interpreter variants of the kernel."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, K, N = 4, 96, 9
+    for kw in ({"no_builtin": True}, {"force_interpreter": True}):
+        cfg = rv.MPCConfig(N=N, K=K, **kw)
+        states = np.empty((B, 16)); U = np.empty((B, K, N, 3))
+        for b in range(B):
+            states[b], U[b] = rv.synthetic_problem(K, N, seed=70 + b)
+        d_states = torch.tensor(states, device=dev); d_U = torch.tensor(U, device=dev)
+        with rv.Engine(cfg) as e:
+            d_res = torch.empty((B, e.result_len), dtype=torch.float64, device=dev)
+            e.step_batch_device(B, d_states.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            res = d_res.cpu().numpy()
+            for b in range(B):
+                one = e.step(states[b], U[b])
+                assert one.cost == res[b, 0] and one.index == int(res[b, 1])
+                np.testing.assert_array_equal(one.traj, res[b, 5:].reshape(-1, 2))
+
+
+def test_config4_size_eight_shards_of_4096(rv, orc):
+    """BASELINE configs[3] as far as one GPU can take it: K = 32768 split into 8 contiguous shards of 4096, each rolled
+    out by the sharded step into its slot row, min over the 8 slot images (what the all-reduce leaves), select kernel
+    == the un-sharded Engine(K=32768).step == the oracle's arg-min."""
+    import torch
+    G, Kl, N = 8, 4096, 20
+    K = G * Kl
+    state, U = rv.synthetic_problem(K, N, seed=33)
+    dev = torch.device("cuda", 0)
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    with rv.Engine(rv.MPCConfig(N=N, K=K)) as e:
+        full = e.step(state, U)
+        Jfull = e.rollout_costs(state, U)
+    with rv.Engine(rv.MPCConfig(N=N, K=Kl)) as e:
+        R = e.result_len
+        slots = torch.empty((G, G, R), dtype=torch.int64, device=dev)
+        for g in range(G):
+            e.step_device_sharded(d_state.data_ptr(), d_U[g * Kl:(g + 1) * Kl].data_ptr(), g * Kl, g, G, slots[g].data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        reduced = slots.min(dim=0).values.contiguous()
+        out = torch.empty(R, dtype=torch.float64, device=dev)
+        e.select_device(reduced.data_ptr(), G, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert o[0] == full.cost and int(o[1]) == full.index and np.array_equal(o[2:5], full.u)
+    np.testing.assert_array_equal(o[5:].reshape(-1, 2), full.traj)
+    cfg = rv.MPCConfig(N=N, K=K)
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, rv.default_model()), orc.MPCState.from_array(state), U)
+    assert int(np.argmin(Jo)) == full.index
+    np.testing.assert_allclose(Jfull, Jo, rtol=1e-9)
+    np.testing.assert_allclose(full.traj, trajo[full.index], rtol=1e-9, atol=1e-12)
+
+
+def test_config5_size_closed_loop_10000_steps(rv):
+    """BASELINE configs[4] on one GPU: 10 000 closed-loop steps of Rov_traj_gen case 12 at N=20, K=4096, the model's own
+    (theta, gamma) fed back, within a wall-time bound; spot steps reproduced by stand-alone launches on the recorded state."""
+    import time
+    import torch
+    from rovmpc.closed_loop import run_closed_loop
+    with rv.Engine(rv.MPCConfig(N=20, K=4096)) as e:
+        run_closed_loop(e, 12, 100, feedback=True)
+        t0 = time.perf_counter()
+        rep = run_closed_loop(e, 12, 10000, feedback=True)
+        wall = time.perf_counter() - t0
+        assert rep.steps == 10000 and np.isfinite(rep.cost).all() and np.isfinite(rep.theta_gamma).all()
+        assert rep.wall_s < 1.0 and wall < 30.0, (rep.wall_s, wall)             # ~0.2 s of GPU time (20 us per step)
+        assert rep.real_time_factor > 100
+        assert rep.u.shape == (10000, 3) and rep.theta_gamma.shape == (10001, 2)
+
+
+def test_handoff_timeouts_are_errors_not_wrong_records(rv):
+    """The sharded step's GPU-side waits (collective <- rollout row, rollout <- select that frees the slot row) give up
+    after handoff_timeout_ms.  A give-up must surface as an error of the synchronising call and a NaN cost in the affected
+    record, never as a silently reused row.  Injected on a one-rank RCCL communicator."""
+    import torch
+    from rovmpc.sharded import NativeShardedMPC
+    cfg = rv.MPCConfig(N=20, K=512)
+    dev = torch.device("cuda", 0)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=5)
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    with rv.Engine(cfg) as e:
+        want = e.step(state, U)
+        smpc = NativeShardedMPC(e, rank=0, world=1)
+        e.set_option("handoff_timeout_ms", 200.0)
+        rec = smpc.step_device(d_state, d_U); smpc.synchronize()
+        assert rec.cpu().numpy()[0] == want.cost
+        # (1) one rollout does not publish its row: the collective of that step gives up -> error + NaN record
+        e.set_option("inject_skip_rolled", 1)
+        bad = smpc.step_device(d_state, d_U)
+        with pytest.raises(rv.RovmpcError, match="never saw its rollout"):
+            smpc.synchronize()
+        assert np.isnan(bad.cpu().numpy()[0])
+        # the error word was consumed: the next steps are clean again
+        good = [smpc.step_device(d_state, d_U) for _ in range(4)]
+        smpc.synchronize()
+        assert all(g.cpu().numpy()[0] == want.cost for g in good)
+        # (2) one select does not free its slot row: four steps later the rollout that needs the row gives up
+        e.set_option("inject_skip_consumed", 1)
+        outs = [smpc.step_device(d_state, d_U) for _ in range(4)]      # the step that loses its 'consumed' is itself fine
+        smpc.synchronize()
+        assert all(o.cpu().numpy()[0] == want.cost for o in outs)
+        late = smpc.step_device(d_state, d_U)                          # same slot again: its row was never freed
+        with pytest.raises(rv.RovmpcError, match="frees its slot row"):
+            smpc.synchronize()
+        assert np.isnan(late.cpu().numpy()[0])
+        again = smpc.step_device(d_state, d_U); smpc.synchronize()
+        assert again.cpu().numpy()[0] == want.cost
+        smpc.close()
+
 
 
 def test_mpc_step_surface_and_closed_loop(rv):

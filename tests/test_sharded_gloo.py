@@ -90,3 +90,32 @@ def test_ordered_keys_roundtrip_and_order():
     assert best[0] == 0.5 and best[1] == 3.0             # cost tie -> lower global index wins
     assert torch.equal(best, r2)
     assert [shard_bounds(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+def test_bench_launches_its_own_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2` is a plain command: the parent starts the two ranks as children (torch.distributed.run),
+    relays rank 0's single JSON line and exits with their status.  Protocol-only ranks (gloo, no GPU, fabricated
+    records) exercise launcher + rendezvous + pack / all-reduce(min) / select + the relay."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--backend", "gloo", "--protocol-only", "--K", "64", "--N", "5"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["ranks_agree"] is True and d["records_are_the_global_min"] is True
+    assert d["config"]["collective_fallback_reason"] is None
+
+
+def test_bench_parent_reports_a_failed_rank():
+    """A rank that dies must surface as a non-zero exit of the plain command, not as a hang or a silent success."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+                        "--backend", "gloo", "--protocol-only", "--K", "64", "--N", "5"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, ROVMPC_BENCH_TEST_FAIL_RANK="1"))
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
