@@ -80,6 +80,8 @@ template <typename T> struct RolloutArgs {
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
     int plant_feedback;           // 1: keep the model's own (theta, gamma) = first predicted node of this step's winner
+    unsigned long long *step_seq; // persistent closed loop (closed_loop_kernel): after the plant update the sweeper publishes
+    unsigned long long step_next; //   *step_seq = step_next, which the other workgroups poll before their next step; null otherwise
     int NT, nblocks;              // launch geometry (blockDim / gridDim are dependent loads through the implicit arguments)
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
@@ -199,7 +201,9 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     // is pending -- no ticket counter, no fence, and the other workgroups leave as soon as they have published.
     {
         int j = 0;
-        const unsigned long long give_up = wall_clock64() + 6000000000ULL;      // 60 s of the 100 MHz clock
+        // 60 s of the 100 MHz clock; inside the persistent loop the hand-off timeout (a workgroup that gave up its own wait
+        // never publishes, and the grid has to drain)
+        const unsigned long long give_up = wall_clock64() + (a.step_seq ? a.handoff_ticks : 6000000000ULL);
         for (unsigned it = 1;; ++it) {
             bool pending = false;
             for (;;) {
@@ -279,15 +283,23 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     if (a.plant_next && tid < 16) {
         const double *plant_next = a.plant_next;
         double *plant_state = a.plant_state;
+        // persistent loop: the other workgroups read the state inside this launch -> write-through stores
+        auto put = [&](int i, double v) { if (a.step_seq) st_agent(&plant_state[i], v); else plant_state[i] = v; };
         if (!a.plant_feedback) {
-            plant_state[tid] = plant_next[tid];
+            put(tid, plant_next[tid]);
         } else if (tid < 12) {
-            plant_state[tid] = plant_next[tid];
+            put(tid, plant_next[tid]);
         } else if (tid == 12) {
-            const double th = plant_state[12], ga = plant_state[13];
-            plant_state[14] = th; plant_state[15] = ga;
-            plant_state[12] = ld_agent(&bt[2]); plant_state[13] = ld_agent(&bt[3]);   // (theta, gamma) of node 1
+            const double th = a.step_seq ? ld_agent(&plant_state[12]) : plant_state[12];
+            const double ga = a.step_seq ? ld_agent(&plant_state[13]) : plant_state[13];
+            put(14, th); put(15, ga);
+            put(12, ld_agent(&bt[2])); put(13, ld_agent(&bt[3]));   // (theta, gamma) of node 1
         }
+    }
+    if (a.step_seq && tid < 64) {
+        // every store of the new state came from this wave: drain them, then the step number (the data's flag)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) st_agent(a.step_seq, a.step_next);
     }
 }
 
@@ -333,17 +345,25 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     return e;
 }
 
-template <typename T, int MODEL, int VT>
+template <typename T, int MODEL, int VT, bool PERSIST = false>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
-    const int N = a.N, CK = a.CK, K = a.K;
-    const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
+    // Inside the persistent loop the roots of every index, address and bound below are made opaque once per step
+    // (empty asm): otherwise the optimiser hoists the step-invariant part of the whole body out of the step loop and
+    // keeps it live across it (measured: 256 VGPRs + scratch instead of 148).
+    auto opaque_s = [](int v) { if (PERSIST) asm volatile("" : "+s"(v)); return v; };
+    const int N = opaque_s(a.N), CK = opaque_s(a.CK), K = opaque_s(a.K);
+    const int cks = opaque_s(a.ck_shift), ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
-    const RolloutConsts<T> &kk = *a.k;
-    const int tid = threadIdx.x, NT = a.NT;
+    const RolloutConsts<T> *kkp = a.k;
+    if (PERSIST) asm volatile("" : "+s"(kkp));
+    const RolloutConsts<T> &kk = *kkp;
+    int tid_ = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, NT = opaque_s(a.NT);
     const int k0 = blockIdx.x * CK;
     // Batched launch (rovmpc_step_batch_device): blockIdx.y = problem.  Every per-problem array is the single-problem
     // array repeated B times; a problem's workgroups, granules, sweeper and record never touch another problem's.
@@ -371,7 +391,22 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(0);
     // state: declared here (the gamma lambdas capture it), loaded after the controls' loads are in flight
     T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
-    const double *sd = a.state + (size_t)prob * ROVMPC_STATE_LEN;
+    // Persistent closed loop: the state was written by another workgroup inside this launch (the sweeper of the previous
+    // step), so it is fetched once with agent-scope loads into LDS and read from there; otherwise plain (scalar) loads.
+    __shared__ double s_state[ROVMPC_STATE_LEN];
+    if (PERSIST) {
+        if (tid < ROVMPC_STATE_LEN) s_state[tid] = ld_agent(&a.state[tid]);
+        __syncthreads();
+    }
+    const double *sdg = a.state + (size_t)prob * ROVMPC_STATE_LEN;
+    // state element i as a wave-uniform value (the LDS copy is made scalar again: one readfirstlane per half)
+    auto sd_at = [&](int i) -> double {
+        if (!PERSIST) return sdg[i];
+        const double v = s_state[i];
+        const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(__double_as_longlong(v) & 0xffffffffLL));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)__double_as_longlong(v) >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
 
     // Compiled-in model: dgamma/dt = x15 - x17 reads gamma and its delay slot only -- no control, no
     // theta -- so the gamma path is the SAME for every candidate and needs nothing but the state.  One
@@ -477,10 +512,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; }
     }
     // state (uniform loads), behind the controls' loads
-    P0x = (T)sd[0]; P0y = (T)sd[1]; P0z = (T)sd[2];
-    V0x = (T)sd[6]; V0y = (T)sd[7]; V0z = (T)sd[8];
-    A0x = (T)sd[9]; A0y = (T)sd[10]; A0z = (T)sd[11];
-    th0 = (T)sd[12]; ga0 = (T)sd[13]; thm0 = (T)sd[14]; gam0 = (T)sd[15];
+    P0x = (T)sd_at(0); P0y = (T)sd_at(1); P0z = (T)sd_at(2);
+    V0x = (T)sd_at(6); V0y = (T)sd_at(7); V0z = (T)sd_at(8);
+    A0x = (T)sd_at(9); A0y = (T)sd_at(10); A0z = (T)sd_at(11);
+    th0 = (T)sd_at(12); ga0 = (T)sd_at(13); thm0 = (T)sd_at(14); gam0 = (T)sd_at(15);
+    const T P1x0 = (T)sd_at(3), P1y0 = (T)sd_at(4), P1z0 = (T)sd_at(5);
     __syncthreads();
 
     RV_STAMP(1);
@@ -508,7 +544,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const int n = q < N + 1 - p2rem ? p2rem + q : q - (N + 1 - p2rem);
         // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
         // sequential order by the item itself (independent LDS reads, no scan, no extra barrier)
-        T Px = (T)sd[3], Py = (T)sd[4], Pz = (T)sd[5];
+        T Px = P1x0, Py = P1y0, Pz = P1z0;
         {
             const T *u = &sU[c * US];
             for (int j = 0; j < n; ++j) {
@@ -551,7 +587,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T Qx, Qy, Qz;                        // position of node m, bit-equal to its own sequential sum
             if (n == 0) { Qx = Px + kk.vs_h * um[0]; Qy = Py + kk.vs_h * um[1]; Qz = Pz + kk.vs_h * um[2]; }
             else {
-                Qx = (T)sd[3]; Qy = (T)sd[4]; Qz = (T)sd[5];
+                Qx = P1x0; Qy = P1y0; Qz = P1z0;
                 for (int j = 0; j < m; ++j) { Qx = Qx + kk.vs_h * um[3 * j]; Qy = Qy + kk.vs_h * um[3 * j + 1]; Qz = Qz + kk.vs_h * um[3 * j + 2]; }
             }
             T Vx, Vy, Vz, Wx, Wy, Wz;
@@ -1150,6 +1186,57 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT>(a);
+}
+
+// ---- persistent closed loop --------------------------------------------------------------------------------------
+// BASELINE config 5 on one GPU: ONE launch runs all T steps.  The grid is the single-step grid (every workgroup must be
+// resident: the host checks nblocks against the device's capacity); per step each workgroup does exactly what the
+// single-step kernel does, on candidate batch pools[i % n_pools], and publishes its best as granules tagged with epoch
+// a.epoch + i.  The sweeping workgroup reduces them, writes record i and the state of step i + 1 (write-through) and
+// publishes the step number; the others poll that number before they read the state -- the granule epoch and the step
+// number together are the grid-wide step barrier.  Every wait is bounded by a.handoff_ticks: a workgroup that gives up
+// raises ERR_SWEEP and leaves, the sweeper's bounded sweep follows, and the grid drains.
+struct PersistArgs {
+    long long T;                      // steps
+    const double *exo;                // [T][16] measured rows (rovmpc_closed_loop_device)
+    unsigned long long *step_seq;     // states published so far (0 at launch: state 0 is already in a.state)
+    long long pool_elems;             // K * N * 3
+    int n_pools;
+};
+
+template <typename T, int MODEL, int VT>
+RV_DEV void closed_loop_body(const RolloutArgs<T> &a0, const PersistArgs &p) {
+    const int R = 5 + 2 * (a0.N + 1);
+    int pool = 0;
+    for (long long i = 0; i < p.T; ++i) {
+        if (i > 0) {
+            bool gave_up = false;
+            if (threadIdx.x == 0) {
+                const unsigned long long give_up = wall_clock64() + a0.handoff_ticks;
+                while (ld_agent(p.step_seq) < (unsigned long long)i) {
+                    if (wall_clock64() > give_up) { gave_up = true; raise_error(a0.err, ERR_SWEEP); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            // (also the barrier that frees the LDS image of the previous step)
+            if (__syncthreads_or(gave_up)) return;
+        }
+        RolloutArgs<T> a = a0;
+        a.U = a0.U + (size_t)pool * p.pool_elems;
+        a.result = a0.result + (size_t)i * R;
+        a.epoch = a0.epoch + (unsigned)i;
+        a.plant_next = i + 1 < p.T ? p.exo + (size_t)(i + 1) * ROVMPC_STATE_LEN : nullptr;
+        a.plant_state = const_cast<double *>(a0.state);
+        a.step_seq = p.step_seq; a.step_next = (unsigned long long)(i + 1);
+        rollout_body<T, MODEL, VT, true>(a);
+        if (++pool == p.n_pools) pool = 0;
+    }
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+closed_loop_kernel(const RolloutArgs<T> a, const PersistArgs p) {
+    closed_loop_body<T, MODEL, VT>(a, p);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

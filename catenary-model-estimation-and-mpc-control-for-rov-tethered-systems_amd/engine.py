@@ -280,7 +280,11 @@ class Engine:
     def closed_loop_device(self, d_exo: int, T: int, d_state: int, d_pools: int, n_pools: int, d_results: int,
                            k_offset: int = 0, feedback: bool = False, stream: int = 0, persistent: bool = False):
         if persistent:
-            raise RovmpcError(-4, "persistent closed loop is not built yet")
+            if k_offset:
+                raise ValueError("the persistent loop is single-GPU (k_offset must be 0)")
+            self._check(self.lib.rovmpc_closed_loop_persistent_device(self._h, d_exo, T, d_state, d_pools, n_pools,
+                                                                      int(feedback), d_results, stream))
+            return
         self._check(self.lib.rovmpc_closed_loop_device(self._h, d_exo, T, d_state, d_pools, n_pools, k_offset,
                                                        int(feedback), d_results, stream))
 

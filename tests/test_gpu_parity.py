@@ -871,6 +871,40 @@ def test_config5_size_closed_loop_10000_steps(rv):
         assert rep.u.shape == (10000, 3) and rep.theta_gamma.shape == (10001, 2)
 
 
+@pytest.mark.parametrize("feedback", [False, True])
+@pytest.mark.parametrize("K,N,steps,kw", [(4096, 20, 300, {}), (1024, 20, 64, {"dtype": "f32"}), (512, 12, 40, {"no_builtin": True}),
+                                           (4096, 20, 40, {"vt_mode": 0})])
+def test_persistent_closed_loop_equals_launch_per_step(rv, K, N, steps, kw, feedback):
+    """rovmpc_closed_loop_persistent_device (one launch, T steps, in-kernel step hand-off) must reproduce the records of
+    the launch-per-step loop bit for bit, with measured rows and with the model's own (theta, gamma) fed back."""
+    from rovmpc.closed_loop import run_closed_loop
+    with rv.Engine(rv.MPCConfig(N=N, K=K, **kw)) as e:
+        a = run_closed_loop(e, 12, steps, feedback=feedback, persistent=False)
+        b = run_closed_loop(e, 12, steps, feedback=feedback, persistent=True)
+        c = run_closed_loop(e, 12, steps, feedback=feedback, persistent=True)        # epochs advance, buffers are reusable
+        e.device_status()                                                             # no hand-off gave up
+    for r in (b, c):
+        if kw.get("dtype") == "f32":
+            # two instantiations of the fp32 body: the compiler's fma contraction may differ in the last bit
+            np.testing.assert_allclose(r.cost, a.cost, rtol=2e-6)
+            np.testing.assert_allclose(r.theta_gamma, a.theta_gamma, rtol=2e-6, atol=1e-9)
+            assert (np.any(a.u != r.u, axis=1).mean() < 0.05) or not feedback
+        else:
+            assert np.array_equal(a.cost, r.cost) and np.array_equal(a.u, r.u) and np.array_equal(a.theta_gamma, r.theta_gamma)
+    assert np.isfinite(a.cost).all()
+    assert np.array_equal(b.cost, c.cost) and np.array_equal(b.u, c.u)
+
+
+def test_persistent_closed_loop_refuses_what_it_cannot_hold(rv):
+    from rovmpc.closed_loop import run_closed_loop
+    with rv.Engine(rv.MPCConfig(N=20, K=8192)) as e:             # more workgroups than compute units: not wholly resident
+        with pytest.raises(rv.RovmpcError, match="resident"):
+            run_closed_loop(e, 12, 10, persistent=True)
+    with rv.Engine(rv.MPCConfig(N=8, K=64, force_interpreter=True)) as e:
+        with pytest.raises(rv.RovmpcError, match="interpreter"):
+            run_closed_loop(e, 12, 10, persistent=True)
+
+
 def test_handoff_timeouts_are_errors_not_wrong_records(rv):
     """The sharded step's GPU-side waits (collective <- rollout row, rollout <- select that frees the slot row) give up
     after handoff_timeout_ms.  A give-up must surface as an error of the synchronising call and a NaN cost in the affected
