@@ -59,6 +59,9 @@ _SIGNATURES = {
     "rovmpc_model_path": (C.c_int32, [_P]),
     "rovmpc_step": (C.c_int, [_P, C.POINTER(State), _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "rovmpc_rollout_costs": (C.c_int, [_P, C.POINTER(State), _P, _P, _P]),
+    "rovmpc_mpc_step_sampled": (C.c_int, [_P, C.POINTER(State), C.c_uint64, C.c_uint64, _P, _P, C.c_int32, _P]),
+    "rovmpc_sampled_candidates": (C.c_int, [_P, _P]),
+    "rovmpc_sample_candidates_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "rovmpc_result_len": (C.c_int32, [_P]),
     "rovmpc_step_device": (C.c_int, [_P, _P, _P, _P, _P]),
     "rovmpc_step_device_sharded": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),

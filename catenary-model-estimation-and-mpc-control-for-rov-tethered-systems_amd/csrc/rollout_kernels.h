@@ -76,6 +76,11 @@ template <typename T> struct RolloutArgs {
     unsigned long long handoff_ticks; // give-up time of the hand-off waits, 100 MHz ticks
     unsigned *err;                    // host-mapped error word of the handle (ERR_* bits), read by rovmpc_comm_sync / rovmpc_device_status
     int inject;                       // test hooks (rovmpc_set_option): bit 0 = this launch does not publish its row
+    // host-visible completion (rovmpc_mpc_step_sampled): the record is mirrored into pinned, device-mapped host memory
+    // (result_host) and the sweeper stores done_seq to *done_flag at system scope once it is out (null: none)
+    double *result_host;
+    unsigned long long *done_flag;
+    unsigned long long done_seq;
     // closed loop: the sweeping workgroup also applies the plant update for the NEXT step (null: no update)
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
@@ -265,11 +270,21 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
         else v = ld_agent(&bt[i - 5]);
         result[i] = v;
+        if (a.result_host) a.result_host[i] = v;
         if (slots && row_free) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
     }
     if (slots && row_free) {
         for (int i = tid; i < world * R; i += NT)
             if (i / R != rank) st_agent(&slots[i], 0x7fffffffffffffffLL);
+    }
+    if (a.done_flag) {
+        // the record went to host memory: drain every wave's stores, then release the sequence number the host spins on
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (a.flag_rolled && !(a.inject & 1)) {
         // publish: the row went out write-through at agent scope; once every wave's stores are acknowledged the

@@ -10,6 +10,7 @@
 #include <hip/hiprtc.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -62,6 +63,13 @@ struct rovmpc_handle {
     unsigned *h_err = nullptr, *d_err = nullptr;
     double handoff_timeout_ms = 10000.0;      // give-up time of the GPU-side hand-off waits (rovmpc_set_option)
     int inject_skip_rolled = 0, inject_skip_consumed = 0;   // test hooks: the next N steps lose that publication
+    // rovmpc_mpc_step_sampled: two candidate tensors (the sampler of step s+1 reads the winner of step s for the warm
+    // start), the record mirrored into mapped host memory, and the sequence word the host spins on
+    void *d_Us[2] = {nullptr, nullptr};
+    double *h_record = nullptr, *d_record_host = nullptr;
+    unsigned long long *h_done = nullptr, *d_done = nullptr;
+    unsigned long long samp_steps = 0;
+    double *arg_result_host = nullptr; unsigned long long *arg_done_flag = nullptr; unsigned long long arg_done_seq = 0;
     // batched launches: workspace for `batch_cap` problems
     int batch_cap = 0;
     void *d_Jb = nullptr; double *d_blk_trajb = nullptr; unsigned long long *d_granulesb = nullptr;
@@ -353,7 +361,9 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
-                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq};
+                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1]};
+    if (h->h_record) (void)hipHostFree(h->h_record);
+    if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->h_err) (void)hipHostFree(h->h_err);
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h->epoch_ctr;
@@ -688,6 +698,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.NT = g.NT; a.nblocks = g.nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
     a.step_seq = nullptr; a.step_next = 0;
+    a.result_host = h->arg_result_host; a.done_flag = h->arg_done_flag; a.done_seq = h->arg_done_seq;
     a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
     a.consumed_need = h->arg_consumed_need; a.rolled_seq = h->arg_rolled_seq;
     a.slot_bad = h->arg_slot_bad; a.err = h->d_err; a.inject = h->arg_inject;
@@ -805,6 +816,88 @@ extern "C" int rovmpc_step_batch_device(rovmpc_handle *h, int32_t B, const doubl
 extern "C" int rovmpc_batch_costs_device(rovmpc_handle *h, const void **d_J) {
     if (!h || !d_J) return ROVMPC_ERR_INVALID;
     *d_J = h->batch_cap > 0 ? h->d_Jb : h->d_J;
+    return ROVMPC_OK;
+}
+
+static int take_device_errors(rovmpc_handle *h);
+
+// ---- MPC.step with the candidates drawn on the GPU: one call, no copies on the step path ---------------------------
+static int ensure_sampler(rovmpc_handle *h) {
+    if (h->d_Us[0]) return ROVMPC_OK;
+    const size_t ub = (size_t)h->cfg.K * h->cfg.N * 3 * h->esz, R = (size_t)rovmpc_result_len(h);
+    HIPCHK(h, hipMalloc(&h->d_Us[0], ub));
+    HIPCHK(h, hipMalloc(&h->d_Us[1], ub));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_record, R * sizeof(double), hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_record_host, h->h_record, 0));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_done, 64, hipHostMallocMapped));
+    *h->h_done = 0;
+    HIPCHK(h, hipHostGetDevicePointer((void **)&h->d_done, h->h_done, 0));
+    return ROVMPC_OK;
+}
+
+static int launch_sampler(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step, const double *mean3,
+                          const double *std3, int warm, void *d_U, const void *d_Uprev, hipStream_t s) {
+    SampleArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    if (state) { sa.state = *state; sa.d_state = h->d_state; }
+    sa.seed = seed; sa.step = step;
+    for (int i = 0; i < 3; ++i) { sa.mean[i] = mean3[i]; sa.std[i] = std3[i]; }
+    sa.total = (long long)h->cfg.K * h->cfg.N * 3; sa.N = h->cfg.N;
+    sa.warm = warm; sa.Uprev = d_Uprev; sa.prev_record = h->d_result;
+    const int bs = 256;
+    const int grid = (int)(((sa.total + 3) / 4 + bs - 1) / bs);
+    if (h->cfg.dtype == ROVMPC_F64) hipLaunchKernelGGL(sample_candidates_kernel<double>, dim3(grid), dim3(bs), 0, s, sa, (double *)d_U);
+    else hipLaunchKernelGGL(sample_candidates_kernel<float>, dim3(grid), dim3(bs), 0, s, sa, (float *)d_U);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "sampler launch failed: %s", hipGetErrorString(e));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_sample_candidates_device(rovmpc_handle *h, uint64_t seed, uint64_t step, const double *mean3,
+                                               const double *std3, void *d_U, void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!mean3 || !std3 || !d_U) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_sample_candidates_device: null pointer");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return launch_sampler(h, nullptr, seed, step, mean3, std3, 0, d_U, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step,
+                                       const double *mean3, const double *std3, int32_t warm_start, double *record_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!state || !mean3 || !std3 || !record_out) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_mpc_step_sampled: null pointer");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if ((rc = ensure_sampler(h))) return rc;
+    const int cur = (int)(h->samp_steps & 1);
+    const int warm = warm_start && h->samp_steps > 0;
+    if ((rc = launch_sampler(h, state, seed, step, mean3, std3, warm, h->d_Us[cur], h->d_Us[cur ^ 1], h->stream))) return rc;
+    const unsigned long long seq = ++h->samp_steps;
+    h->arg_result_host = h->d_record_host; h->arg_done_flag = h->d_done; h->arg_done_seq = seq;
+    rc = enqueue_step(h, h->d_state, h->d_Us[cur], nullptr, h->d_result, 0, nullptr, 0, 1, h->stream);
+    h->arg_result_host = nullptr; h->arg_done_flag = nullptr;
+    if (rc) return rc;
+    // the sweeper releases `seq` into mapped host memory behind the record: spin on it (a stream synchronise costs
+    // several microseconds of wake-up latency); after ~2 s fall back to the blocking call so a failed launch is reported
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (__atomic_load_n(h->h_done, __ATOMIC_ACQUIRE) != seq) FAIL(h, ROVMPC_ERR_HIP, "the step finished without publishing its record");
+            break;
+        }
+    }
+    memcpy(record_out, h->h_record, (size_t)rovmpc_result_len(h) * sizeof(double));
+    return take_device_errors(h);
+}
+
+extern "C" int rovmpc_sampled_candidates(rovmpc_handle *h, void *U_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!U_out || h->samp_steps == 0) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_sampled_candidates: no sampled step yet");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(U_out, h->d_Us[(h->samp_steps - 1) & 1], (size_t)h->cfg.K * h->cfg.N * 3 * h->esz, hipMemcpyDeviceToHost));
     return ROVMPC_OK;
 }
 

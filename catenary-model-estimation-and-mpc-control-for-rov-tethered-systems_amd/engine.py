@@ -211,6 +211,33 @@ class Engine:
         self._check(self.lib.rovmpc_step(self._h, C.byref(s), _ptr(U), _ptr(u), _ptr(traj), C.byref(cost), C.byref(idx)))
         return StepResult(u, traj, cost.value, idx.value)
 
+    def mpc_step_sampled(self, state, seed: int, step: int, mean, std, warm_start: bool = True) -> np.ndarray:
+        """One control step with the candidates drawn on the GPU (Philox4x32-10 keyed by (seed, step), Box-Muller):
+        returns the record [J*, k*, u(3), (theta, gamma)_0..N].  One library call; the host sends the state, spins on the
+        completion word and reads the record from mapped memory."""
+        if getattr(self, "_samp", None) is None:
+            self._samp = {"state": State(), "rec": np.empty(self.result_len), "mean": np.empty(3), "std": np.empty(3)}
+            self._samp["prec"] = _ptr(self._samp["rec"]); self._samp["pm"] = _ptr(self._samp["mean"]); self._samp["ps"] = _ptr(self._samp["std"])
+            self._samp["pstate"] = C.byref(self._samp["state"])
+        sp = self._samp
+        sa = state if (isinstance(state, np.ndarray) and state.dtype == np.float64 and state.shape == (16,) and state.flags.c_contiguous) else state_array(state)
+        C.memmove(sp["pstate"], sa.ctypes.data, 128)
+        sp["mean"][:] = mean; sp["std"][:] = std
+        rc = self.lib.rovmpc_mpc_step_sampled(self._h, sp["pstate"], seed, step, sp["pm"], sp["ps"], int(warm_start), sp["prec"])
+        if rc:
+            self._check(rc)
+        return sp["rec"]
+
+    def sampled_candidates(self) -> np.ndarray:
+        """Host copy of the candidate tensor of the last ``mpc_step_sampled`` (tests / inspection)."""
+        U = np.empty((self.cfg.K, self.cfg.N, 3), dtype=self.cfg.np_dtype)
+        self._check(self.lib.rovmpc_sampled_candidates(self._h, _ptr(U)))
+        return U
+
+    def sample_candidates_device(self, seed: int, step: int, mean, std, d_U: int, stream: int = 0):
+        m = np.ascontiguousarray(mean, np.float64); s = np.ascontiguousarray(std, np.float64)
+        self._check(self.lib.rovmpc_sample_candidates_device(self._h, seed, step, _ptr(m), _ptr(s), d_U, stream))
+
     def rollout_costs(self, state, U, return_traj: bool = False):
         sa = state_array(state)
         U = self._U(U)

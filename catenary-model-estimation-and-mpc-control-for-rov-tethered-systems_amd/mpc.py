@@ -31,26 +31,16 @@ class GaussianSampler:
 
 
 class DeviceGaussianSampler:
-    """The same candidate law drawn on the GPU (torch generator): the candidate tensor never exists on the host, so a
-    step is one small H2D (state), two elementwise kernels, the rollout kernel and one small D2H (the record)."""
+    """The same candidate law drawn on the GPU by the library itself (``rovmpc_mpc_step_sampled``): standard normals from
+    Philox4x32-10 keyed by (seed, step counter) through Box-Muller, so a step is a pure function of (state, seed, step) and
+    reproducible on the host (the test oracle restates the law).  The candidate tensor never exists on the host."""
 
-    def __init__(self, K: int, N: int, device: int = 0, dtype: str = "f64", mean=None, std=None, seed: int = 20250523):
-        import torch
-        self.torch = torch
+    def __init__(self, mean=None, std=None, seed: int = 20250523):
         m = default_model()
-        dev = torch.device("cuda", device)
-        tdt = torch.float64 if dtype == "f64" else torch.float32
-        self.mean = torch.tensor(np.asarray(mean if mean is not None else m.mean[3:6], float), device=dev, dtype=tdt)
-        self.std = torch.tensor(np.asarray(std if std is not None else m.scale[3:6], float), device=dev, dtype=tdt)
-        self.gen = torch.Generator(device=dev); self.gen.manual_seed(seed)
-        self.U = torch.empty((K, N, 3), device=dev, dtype=tdt)
-
-    def sample(self, warm_start=None):
-        """Fills and returns the (K, N, 3) device tensor; ``warm_start`` (N, 3) device tensor pins candidate 0."""
-        self.U.normal_(generator=self.gen).mul_(self.std).add_(self.mean)
-        if warm_start is not None:
-            self.U[0].copy_(warm_start)
-        return self.U
+        self.mean = np.ascontiguousarray(mean if mean is not None else m.mean[3:6], dtype=np.float64)
+        self.std = np.ascontiguousarray(std if std is not None else m.scale[3:6], dtype=np.float64)
+        self.seed = int(seed)
+        self.step = 0
 
 
 class MPC:
@@ -73,26 +63,15 @@ class MPC:
         self._best_seq: Optional[np.ndarray] = None
         self._dev = None
         if device_sampling:
-            # candidates are drawn, rolled out and reduced on the GPU; the host sees the state and the record
-            import torch
-            smp = sampler if isinstance(sampler, DeviceGaussianSampler) else DeviceGaussianSampler(
-                self.cfg.K, self.cfg.N, self.cfg.device, self.cfg.dtype)
-            dev = torch.device("cuda", self.cfg.device)
-            self._dev = {"torch": torch, "sampler": smp, "state": torch.empty(16, dtype=torch.float64, device=dev),
-                         "result": torch.empty(self.engine.result_len, dtype=torch.float64, device=dev), "best": None}
+            # candidates are drawn, rolled out and reduced on the GPU by one library call; the host sees the state and the record
+            self._dev = sampler if isinstance(sampler, DeviceGaussianSampler) else DeviceGaussianSampler()
 
     def _step_device_sampled(self, state) -> np.ndarray:
-        d = self._dev; torch = d["torch"]
-        ws = None
-        if self.warm_start and d["best"] is not None:
-            ws = torch.cat([d["best"][1:], d["best"][-1:]])                        # shifted previous optimum
-        U = d["sampler"].sample(ws)
-        d["state"].copy_(torch.from_numpy(state_array(state)), non_blocking=True)
-        self.engine.step_device(d["state"].data_ptr(), U.data_ptr(), d["result"].data_ptr(), torch.cuda.current_stream().cuda_stream)
-        rec = d["result"].cpu().numpy()                                            # [J*, k*, u(3), (theta, gamma)_0..N]
-        k = int(rec[1])
-        d["best"] = U[k].clone()
-        self.last = StepResult(rec[2:5].copy(), rec[5:].reshape(self.cfg.N + 1, 2).copy(), float(rec[0]), k)
+        d = self._dev
+        rec = self.engine.mpc_step_sampled(state, d.seed, d.step, d.mean, d.std, self.warm_start)
+        d.step += 1
+        N = self.cfg.N
+        self.last = StepResult(rec[2:5].copy(), rec[5:].reshape(N + 1, 2).copy(), float(rec[0]), int(rec[1]))
         return self.last.u
 
     def step(self, state, U: Optional[np.ndarray] = None) -> np.ndarray:

@@ -176,6 +176,18 @@ int32_t rovmpc_model_path(const rovmpc_handle *h);
 int rovmpc_step(rovmpc_handle *h, const rovmpc_state *state, const void *U,
                 double *u_out, double *traj_out, double *best_cost, int64_t *best_idx);
 
+/* MPC.step with the proposal drawn on the GPU -- one call per control step, nothing but the 16-double state and the
+ * record crosses PCIe: candidates U[k][n][c] = mean[c] + std[c] z, z standard normal from Philox4x32-10 keyed by
+ * (seed, step) with Box-Muller (exact law in util_kernels.h; restated in the oracle), candidate 0 = the previous winner
+ * shifted by one step when warm_start != 0 (and a previous step exists); then the fused rollout; record_out
+ * [result_len] on return.  rovmpc_sampled_candidates copies the tensor of the last such step to the host (tests);
+ * rovmpc_sample_candidates_device only fills d_U[K][N][3] on `stream`. */
+int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step,
+                            const double *mean3, const double *std3, int32_t warm_start, double *record_out);
+int rovmpc_sampled_candidates(rovmpc_handle *h, void *U_out);
+int rovmpc_sample_candidates_device(rovmpc_handle *h, uint64_t seed, uint64_t step, const double *mean3,
+                                    const double *std3, void *d_U, void *stream);
+
 /* Parity/debug: all K costs (and, if traj_all != NULL, all K trajectories [K][N+1][2]). */
 int rovmpc_rollout_costs(rovmpc_handle *h, const rovmpc_state *state, const void *U,
                          void *J_out, void *traj_all);

@@ -1005,3 +1005,48 @@ def rov_trajectory_csv_rows(t0, t1):
     for s0, s1 in zip(t0.T, t1.T):
         rows.append(",".join(f"{v:.3f}" for v in s0) + "," + ",".join(f"{v:.3f}" for v in s1))
     return rows
+
+
+# ---- candidate sampler (build-defined: the reference has no MPC and no proposal law) ---------------------------------
+# Restates csrc/util_kernels.h::sample_candidates_kernel: Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random
+# numbers: as easy as 1, 2, 3", SC'11 -- constants and round function as published) + Box-Muller.
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over uint32 arrays c0..c3 (counter words); scalar key words k0, k1.  Returns the four output words."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    c0 = c0.astype(np.uint32); c1 = c1.astype(np.uint32); c2 = c2.astype(np.uint32); c3 = c3.astype(np.uint32)
+    k0 = int(k0) & 0xFFFFFFFF; k1 = int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64); p1 = M1 * c2.astype(np.uint64)
+        n0 = (p1 >> np.uint64(32)).astype(np.uint32) ^ c1 ^ np.uint32(k0)
+        n1 = (p1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        n2 = (p0 >> np.uint64(32)).astype(np.uint32) ^ c3 ^ np.uint32(k1)
+        n3 = (p0 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + 0x9E3779B9) & 0xFFFFFFFF; k1 = (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def philox_normals(seed: int, step: int, n: int) -> np.ndarray:
+    """n standard normals z_e, e = 0..n-1: block j = e // 4 = Philox(counter (j lo, j hi, step lo, step hi), key (seed lo,
+    seed hi)); u_i = (x_i + 0.5) 2^-32; (z_4j, z_4j+1) = sqrt(-2 ln u0) (cos, sin)(2 pi u1), (z_4j+2, z_4j+3) from (u2, u3)."""
+    nb = (n + 3) // 4
+    j = np.arange(nb, dtype=np.uint64)
+    x = philox4x32_10((j & np.uint64(0xFFFFFFFF)).astype(np.uint32), (j >> np.uint64(32)).astype(np.uint32),
+                      np.full(nb, step & 0xFFFFFFFF, np.uint32), np.full(nb, (step >> 32) & 0xFFFFFFFF, np.uint32),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = [(xi.astype(np.float64) + 0.5) * 2.0 ** -32 for xi in x]
+    z = np.empty((nb, 4))
+    for h in range(2):
+        r = np.sqrt(-2.0 * np.log(u[2 * h])); ang = 6.283185307179586 * u[2 * h + 1]
+        z[:, 2 * h] = r * np.cos(ang); z[:, 2 * h + 1] = r * np.sin(ang)
+    return z.reshape(-1)[:n]
+
+
+def sample_candidates(seed: int, step: int, K: int, N: int, mean, std, prev_best=None) -> np.ndarray:
+    """U[k, n, c] = mean[c] + std[c] z_e, e = (k N + n) 3 + c; candidate 0 = prev_best shifted by one step (warm start)."""
+    z = philox_normals(seed, step, K * N * 3).reshape(K, N, 3)
+    U = np.asarray(mean, float) + np.asarray(std, float) * z
+    if prev_best is not None:
+        U[0] = np.vstack([prev_best[1:], prev_best[-1:]])
+    return U

@@ -781,10 +781,21 @@ def test_batched_problems_equal_single_launches(rv, orc, B, K, N, dtype):
         for b in range(B):
             e.step_device(d_states[b].data_ptr(), d_U[b].data_ptr(), single.data_ptr(), stream)
             torch.cuda.synchronize()
-            assert np.array_equal(single.cpu().numpy(), res[b]), b
+            one = single.cpu().numpy()
+            if dtype == "f64":
+                assert np.array_equal(one, res[b]), b
+            else:
+                # fp32: a batched grid may use another workgroup geometry than the single launch, and the two inlined copies
+                # of the per-node geometry routine (early batch / main round) contract their fp32 FMAs differently: costs can
+                # differ in the last bit between geometries (measured: 8 of 1024, 1 ulp); trajectories never do
+                np.testing.assert_allclose(one[0], res[b, 0], rtol=1e-6)
+                assert one[1] == res[b, 1] or abs(one[0] - res[b, 0]) <= 1e-6 * abs(one[0])
             if b in (0, B - 1):
                 J1 = e.rollout_costs(states[b], U[b])
-                assert np.array_equal(J1, Jall[b])
+                if dtype == "f64":
+                    assert np.array_equal(J1, Jall[b])
+                else:
+                    np.testing.assert_allclose(J1, Jall[b], rtol=1e-6)
     model = rv.default_model()
     for b in (0, B - 1):
         Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(states[b]), U[b].astype(np.float64))
@@ -1003,14 +1014,17 @@ def test_closed_loop_second_order_model(rv):
 
 
 def test_mpc_step_with_device_side_sampling(rv, orc):
-    """MPC(device_sampling=True): candidates drawn on the GPU; the returned control is the arg-min of exactly those
-    candidates (checked against the oracle on a copy of the device tensor), warm start pins candidate 0."""
+    """MPC(device_sampling=True): one library call per step draws the candidates on the GPU (Philox4x32-10 + Box-Muller),
+    rolls them out and returns the record.  The tensor is exactly the oracle's restatement of the law for (seed, step);
+    the returned control is the arg-min of those candidates; warm start pins candidate 0; fp32 too."""
     import time
-    mpc = rv.MPC(N=12, K=256, device_sampling=True)
+    mpc = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
     state, _ = rv.synthetic_problem(256, 12)
-    u = mpc.step(state)
-    U = mpc._dev["sampler"].U.cpu().numpy()
     model = rv.default_model()
+    u = mpc.step(state)
+    U = mpc.engine.sampled_candidates()
+    Uo = orc.sample_candidates(99, 0, 256, 12, model.mean[3:6], model.scale[3:6])
+    np.testing.assert_allclose(U, Uo, rtol=1e-12, atol=1e-9)
     Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, mpc.cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
     k = int(np.argmin(Jo))
     assert mpc.last.index == k and np.array_equal(u, U[k, 0])
@@ -1018,21 +1032,39 @@ def test_mpc_step_with_device_side_sampling(rv, orc):
     np.testing.assert_allclose(mpc.last.traj, trajo[k], rtol=RTOL, atol=1e-13)
     best = U[k].copy()
     u2 = mpc.step(state)
-    U2 = mpc._dev["sampler"].U.cpu().numpy()
+    U2 = mpc.engine.sampled_candidates()
     np.testing.assert_array_equal(U2[0], np.vstack([best[1:], best[-1:]]))       # shifted previous optimum
-    assert not np.array_equal(U2[1], U[1])                                        # fresh draws
-    assert u2.shape == (3,)
-    # the host never touches the candidate tensor: a step is far cheaper than sampling on the host
+    np.testing.assert_allclose(U2[1:], orc.sample_candidates(99, 1, 256, 12, model.mean[3:6], model.scale[3:6])[1:], rtol=1e-12, atol=1e-9)
+    Jo2, _, _ = orc.rollout_vec(oracle_cfg(orc, mpc.cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U2)
+    assert mpc.last.index == int(np.argmin(Jo2)) and np.array_equal(u2, U2[mpc.last.index, 0])
+    # the same (seed, step) gives the same step on a fresh controller; another seed does not
+    mpc_b = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    assert np.array_equal(mpc_b.step(state), u)
+    mpc_c = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=100))
+    mpc_c.step(state)
+    assert not np.array_equal(mpc_c.engine.sampled_candidates(), U)
+    # fp32 tensor: the fp64 draw rounded once
+    mpc_f = rv.MPC(N=12, K=256, dtype="f32", device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    mpc_f.step(state)
+    np.testing.assert_allclose(mpc_f.engine.sampled_candidates(), Uo.astype(np.float32), rtol=2e-7, atol=1e-5)
+    # the stand-alone sampler entry fills a caller's device tensor with the same law
+    import torch
+    dU = torch.empty((256, 12, 3), dtype=torch.float64, device="cuda:0")
+    mpc.engine.sample_candidates_device(99, 0, model.mean[3:6], model.scale[3:6], dU.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dU.cpu().numpy(), U)
+    # the host never touches the candidate tensor: a C2-sized step costs little more than its kernels
     mpc_big = rv.MPC(N=20, K=4096, device_sampling=True)
     st, _ = rv.synthetic_problem(1, 20)
-    for _ in range(5):
+    for _ in range(20):
         mpc_big.step(st)
     t0 = time.perf_counter()
-    for _ in range(50):
+    for _ in range(200):
         mpc_big.step(st)
-    per_step = (time.perf_counter() - t0) / 50
-    assert per_step < 2e-3, per_step
-    mpc.close(); mpc_big.close()
+    per_step = (time.perf_counter() - t0) / 200
+    assert per_step < 60e-6, per_step                                             # measured ~30 us; the bar leaves room for a busy host
+    for m in (mpc, mpc_b, mpc_c, mpc_f, mpc_big):
+        m.close()
 
 
 def test_error_behaviour(rv):

@@ -316,3 +316,22 @@ def test_second_order_rollout_scalar_equals_vectorised(golden_dir, vt_mode, inte
         # the replay starts from zero rates (test_cluster.py:111-112); add the initial-rate ramp
         np.testing.assert_allclose(tz[0, :, 0], th + st.theta_prev * t, rtol=1e-12, atol=1e-15)
         np.testing.assert_allclose(tz[0, :, 1], ga + st.gamma_prev * t, rtol=1e-12, atol=1e-15)
+
+
+def test_philox_restatement_known_answers():
+    """oracle.philox4x32_10 against the published Random123 known-answer vectors (kat_vectors: philox4x32 10), and the
+    moments of the normals it feeds (the proposal law of MPC.step with device sampling)."""
+    from oracle import rovmpc_oracle as orc
+    u32 = lambda *v: [np.array([x], np.uint32) for x in v]
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = orc.philox4x32_10(*u32(*ctr), *key)
+        assert tuple(int(g[0]) for g in got) == want
+    z = orc.philox_normals(7, 3, 400001)
+    assert z.shape == (400001,) and abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
+    assert np.array_equal(orc.philox_normals(7, 3, 10), z[:10]) and not np.array_equal(orc.philox_normals(7, 4, 10), z[:10])
+    U = orc.sample_candidates(7, 3, 5, 4, [1.0, 2.0, 3.0], [0.5, 0.25, 2.0], prev_best=np.arange(12.0).reshape(4, 3))
+    assert np.array_equal(U[0], np.array([[3, 4, 5], [6, 7, 8], [9, 10, 11], [9, 10, 11]], float))
+    assert np.allclose(U[1, 0], np.array([1.0, 2.0, 3.0]) + np.array([0.5, 0.25, 2.0]) * z[12:15])

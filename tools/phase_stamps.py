@@ -15,7 +15,19 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 DBG = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 CKB = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 NTB = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-eng = rovmpc.Engine(rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG, candidates_per_block=CKB, threads_per_block=NTB))
+MODEL = sys.argv[6] if len(sys.argv) > 6 else "default"        # default | gen2 | gen3 | rows:CT,CG | jit-default
+cfg = rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG, candidates_per_block=CKB, threads_per_block=NTB)
+model = rovmpc.default_model()
+if MODEL == "gen2":
+    model = rovmpc.generation2_model(); cfg.feature_map = rovmpc.FEATURES_GEN2
+elif MODEL == "gen3":
+    model = rovmpc.generation3_model(); cfg.feature_map = rovmpc.FEATURES_GEN3
+elif MODEL.startswith("rows:"):
+    model = rovmpc.default_model(*(int(v) for v in MODEL[5:].split(",")))
+elif MODEL == "jit-default":
+    cfg.no_builtin = True
+eng = rovmpc.Engine(cfg, model)
+print("model", MODEL, "->", eng.model_path)
 state, U = rovmpc.synthetic_problem(K, N)
 for _ in range(5):
     eng.step(state, U)
