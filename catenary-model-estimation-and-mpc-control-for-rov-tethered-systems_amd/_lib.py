@@ -81,6 +81,8 @@ _SIGNATURES = {
     "rovmpc_timing_enable": (C.c_int, [_P, C.c_int32]),
     "rovmpc_timing_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rovmpc_predict": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "rovmpc_eval_expression": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P]),
+    "rovmpc_lagrangian_rollout": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int64, _P, C.c_int64, _P]),
     "rovmpc_replay": (C.c_int, [_P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_int32, _P, _P]),
     "rovmpc_solve_catenary": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, _P, _P]),
     "rovmpc_rodrigues": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),

@@ -1194,7 +1194,22 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     RV_STAMP(7);
     if ((int)blockIdx.x != a.sweeper) return;
-    argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
+    if (PERSIST) {
+        argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
+    } else {
+        // The epilogue's own arguments (hand-off flags, slot buffer, plant update, host mirror ...) are cold: one workgroup
+        // reads them once.  Read here through the kernarg segment pointer made opaque, their scalar loads cannot be
+        // scheduled to the top of the kernel, where they would sit in SGPRs across the integration loop (measured: 27
+        // more SGPR spill slots and +0.4 us per step with them loaded up front).  The argument struct is the kernel's
+        // first (or only) parameter in every entry point, so it starts the segment.
+#if defined(__HIP_DEVICE_COMPILE__)
+        const RolloutArgs<T> *ap = (const RolloutArgs<T> *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+#else
+        const RolloutArgs<T> *ap = &a;
+#endif
+        argmin_epilogue<T>(*ap, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
+    }
 }
 
 template <typename T, int MODEL, int VT>

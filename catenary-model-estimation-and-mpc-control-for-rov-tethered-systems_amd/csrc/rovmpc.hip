@@ -1059,6 +1059,58 @@ extern "C" int rovmpc_predict(rovmpc_handle *h, const double *Xs, int64_t n, int
     return ROVMPC_OK;
 }
 
+extern "C" int rovmpc_eval_expression(rovmpc_handle *h, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                                      const double *X, int32_t F, int64_t n, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!code || n < 0 || F < 1 || F > ROVMPC_MAX_FEATURES || n_consts < 0 || n_consts > ROVMPC_MAX_CODE || (n_consts > 0 && !consts) ||
+        (n > 0 && (!X || !out)))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_eval_expression: bad argument");
+    if (const char *why = validate_code(code, n_code, F, n_consts)) FAIL(h, ROVMPC_ERR_INVALID, "program: %s", why);
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dX, dO, dC, dK;
+    const double zero = 0.0;
+    UPLOAD(h, dX, X, (size_t)n * F * sizeof(double));
+    UPLOAD(h, dC, code, (size_t)n_code * sizeof(int32_t));
+    UPLOAD(h, dK, n_consts ? consts : &zero, (size_t)(n_consts ? n_consts : 1) * sizeof(double));
+    HIPCHK(h, dO.alloc((size_t)n * sizeof(double)));
+    const int bs = 256;
+    hipLaunchKernelGGL(predict_kernel, dim3(grid_for(n, bs)), dim3(bs), ROVMPC_MAX_STACK * bs * sizeof(double), h->stream,
+                       dX.as<double>(), (long long)n, (int)F, dC.as<int32_t>(), (int)n_code, dK.as<double>(), dO.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_lagrangian_rollout(rovmpc_handle *h, const int32_t *code_th, int32_t n_th, const int32_t *code_ga, int32_t n_ga,
+                                         const double *consts, int32_t n_consts, const double *time, int64_t T, const double *y0,
+                                         int64_t B, double *out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!code_th || !code_ga || !time || !y0 || !out || T < 1 || B < 1 || n_consts < 0 || n_consts > ROVMPC_MAX_CODE || (n_consts > 0 && !consts))
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_lagrangian_rollout: bad argument");
+    const char *why;
+    if ((why = validate_code(code_th, n_th, 4, n_consts))) FAIL(h, ROVMPC_ERR_INVALID, "theta acceleration program: %s", why);
+    if ((why = validate_code(code_ga, n_ga, 4, n_consts))) FAIL(h, ROVMPC_ERR_INVALID, "gamma acceleration program: %s", why);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dCt, dCg, dK, dT, dY, dO;
+    const double zero = 0.0;
+    UPLOAD(h, dCt, code_th, (size_t)n_th * sizeof(int32_t));
+    UPLOAD(h, dCg, code_ga, (size_t)n_ga * sizeof(int32_t));
+    UPLOAD(h, dK, n_consts ? consts : &zero, (size_t)(n_consts ? n_consts : 1) * sizeof(double));
+    UPLOAD(h, dT, time, (size_t)T * sizeof(double));
+    UPLOAD(h, dY, y0, (size_t)B * 4 * sizeof(double));
+    HIPCHK(h, dO.alloc((size_t)4 * B * T * sizeof(double)));
+    const int bs = 64;
+    hipLaunchKernelGGL(lagrangian_rollout_kernel, dim3(grid_for(B, bs)), dim3(bs), (size_t)(4 + ROVMPC_MAX_STACK) * bs * sizeof(double), h->stream,
+                       dCt.as<int32_t>(), (int)n_th, dCg.as<int32_t>(), (int)n_ga, dK.as<double>(), dT.as<double>(), (long long)T,
+                       dY.as<double>(), (long long)B, dO.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, dO.p, (size_t)4 * B * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_replay(rovmpc_handle *h, const double *Xs, const double *time, int64_t T, double theta0, double gamma0,
                              int32_t integrator, double *theta_out, double *gamma_out) {
     if (!h) return ROVMPC_ERR_INVALID;

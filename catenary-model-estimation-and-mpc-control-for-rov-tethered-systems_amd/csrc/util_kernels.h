@@ -84,6 +84,33 @@ predict_kernel(const double *__restrict__ Xs, long long n, int F, const int32_t 
     if (i < n) out[i] = v;
 }
 
+// Forward integration of a Lagrangian's accelerations (evaluate_lagrangian_on_test.py:59-68), one lane per rollout:
+//   a = dd(theta_{i-1}, gamma_{i-1}, v_{i-1});  v_i = v_{i-1} + a dt_i;  q_i = q_{i-1} + v_{i-1} dt_i,  dt_i = time[i] - time[i-1].
+// out[4][B][T] = theta, gamma, vtheta, vgamma.  The two programs read features x0..x3 = (theta, gamma, vtheta, vgamma).
+__global__ void __launch_bounds__(64)
+lagrangian_rollout_kernel(const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga, const double *consts,
+                          const double *__restrict__ time, long long T, const double *__restrict__ y0, long long B, double *out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int NT = blockDim.x;
+    double *feat = reinterpret_cast<double *>(smem_raw) + threadIdx.x;          // [4][lane]
+    double *stack = reinterpret_cast<double *>(smem_raw) + (size_t)4 * NT + threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * NT + threadIdx.x, b = b0 < B ? b0 : B - 1;   // uniform control flow
+    double th = y0[4 * b], ga = y0[4 * b + 1], vt = y0[4 * b + 2], vg = y0[4 * b + 3];
+    double *o_th = out + (size_t)b * T, *o_ga = out + ((size_t)B + b) * T, *o_vt = out + ((size_t)2 * B + b) * T,
+           *o_vg = out + ((size_t)3 * B + b) * T;
+    if (b0 < B) { o_th[0] = th; o_ga[0] = ga; o_vt[0] = vt; o_vg[0] = vg; }
+    for (long long i = 1; i < T; ++i) {
+        const double dt = time[i] - time[i - 1];                                                  // :60
+        feat[0] = th; feat[NT] = ga; feat[2 * NT] = vt; feat[3 * NT] = vg;
+        const double a_th = interp_eval<double>(code_th, n_th, consts, feat, NT, stack, NT);     // :61
+        const double a_ga = interp_eval<double>(code_ga, n_ga, consts, feat, NT, stack, NT);     // :62
+        const double vt_n = vt + a_th * dt, th_n = th + vt * dt;                                  // :64-65
+        const double vg_n = vg + a_ga * dt, ga_n = ga + vg * dt;                                  // :67-68
+        vt = vt_n; th = th_n; vg = vg_n; ga = ga_n;
+        if (b0 < B) { o_th[i] = th; o_ga[i] = ga; o_vt[i] = vt; o_vg[i] = vg; }
+    }
+}
+
 // Increments of rk4_integration (simulate_rk4_theta_gamma.py:56-66) / integrate_theta_gamma
 // (main_fun.py:757-762) for step i = 1..T-1, both expressions.  inc[0] is unused.
 __global__ void __launch_bounds__(128)

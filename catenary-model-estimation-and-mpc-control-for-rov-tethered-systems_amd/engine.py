@@ -332,6 +332,27 @@ class Engine:
         self._check(self.lib.rovmpc_predict(self._h, _ptr(Xs), Xs.shape[0], which, _ptr(out)))
         return out
 
+    def eval_expression(self, code, consts, X) -> np.ndarray:
+        """A compiled expression (``expr.compile_expression``) on every row of X (n, F)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be (n, F)")
+        c = np.asarray(code, dtype=np.int32); k = np.asarray(consts if len(consts) else [0.0], dtype=np.float64)
+        out = np.empty(X.shape[0])
+        self._check(self.lib.rovmpc_eval_expression(self._h, _ptr(c), len(c), _ptr(k), len(consts), _ptr(X), X.shape[1], X.shape[0], _ptr(out)))
+        return out
+
+    def lagrangian_rollout(self, code_theta, code_gamma, consts, time, y0):
+        """evaluate_lagrangian_on_test.py:59-68 for B initial states y0 (B, 4) = (theta, gamma, vtheta, vgamma): four (B, T) arrays."""
+        time = np.ascontiguousarray(time, dtype=np.float64).reshape(-1)
+        y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, 4)
+        ct = np.asarray(code_theta, dtype=np.int32); cg = np.asarray(code_gamma, dtype=np.int32)
+        k = np.asarray(consts if len(consts) else [0.0], dtype=np.float64)
+        out = np.empty((4, y0.shape[0], time.shape[0]))
+        self._check(self.lib.rovmpc_lagrangian_rollout(self._h, _ptr(ct), len(ct), _ptr(cg), len(cg), _ptr(k), len(consts), _ptr(time),
+                                                       time.shape[0], _ptr(y0), y0.shape[0], _ptr(out)))
+        return out[0], out[1], out[2], out[3]
+
     def replay(self, Xs, time, theta0: float, gamma0: float, integrator: int = _lib.RK4):
         Xs = np.ascontiguousarray(Xs, dtype=np.float64); time = np.ascontiguousarray(time, dtype=np.float64)
         if Xs.ndim != 2 or Xs.shape[1] != self.model.n_features or time.shape != (Xs.shape[0],):

@@ -287,6 +287,20 @@ int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t
  * X is what the reference feeds its models: already-scaled feature rows. */
 int rovmpc_predict(rovmpc_handle *h, const double *Xs, int64_t n, int32_t which, double *out);
 
+/* Any validated bytecode program on n rows X[n][F] (what sympy.lambdify'd expressions are used for in the reference's
+ * evaluation scripts); in particular the Euler-Lagrange residuals EOM_theta / EOM_gamma of a discovered Lagrangian on the
+ * rows (theta, gamma, dtheta, dgamma, ddtheta, ddgamma) of a trajectory -- lagrangian_pipeline_old.py:60-90,
+ * LagrangianModelEstimator.py:158-195; the host derives the two EOM expressions (lagrangian.py). */
+int rovmpc_eval_expression(rovmpc_handle *h, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts,
+                           const double *X, int32_t F, int64_t n, double *out);
+
+/* evaluate_lagrangian_on_test.py:59-68: forward integration of the accelerations solved from the Euler-Lagrange equations,
+ * programs over x0..x3 = (theta, gamma, vtheta, vgamma); B rollouts y0[B][4] over one time grid; out[4][B][T] =
+ * theta, gamma, vtheta, vgamma. */
+int rovmpc_lagrangian_rollout(rovmpc_handle *h, const int32_t *code_theta, int32_t n_code_theta, const int32_t *code_gamma,
+                              int32_t n_code_gamma, const double *consts, int32_t n_consts, const double *time, int64_t T,
+                              const double *y0, int64_t B, double *out);
+
 /* rk4_integration(model, x_input, time, y0) (simulate_rk4_theta_gamma.py:52-68) when
  * integrator == ROVMPC_RK4, integrate_theta_gamma (main_fun.py:735-764) when ROVMPC_EULER;
  * both expressions in one call, either output may be NULL.  Xs[T][F] scaled rows.

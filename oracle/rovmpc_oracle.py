@@ -1050,3 +1050,56 @@ def sample_candidates(seed: int, step: int, K: int, N: int, mean, std, prev_best
     if prev_best is not None:
         U[0] = np.vstack([prev_best[1:], prev_best[-1:]])
     return U
+
+
+# ---- Lagrangian evaluation (lagrangian_pipeline*.py, evaluate_lagrangian_on_test.py) -----------------------
+# The reference's own route: sympy differentiation + lambdify.  sympy is imported lazily (tests / golden generation only).
+
+def el_equations(lagrangian: str):
+    """(EOM_theta, EOM_gamma) as sympy expressions over (th, ga, dth, dga, ddth, ddga): lagrangian_pipeline_old.py:60-83
+    (x0..x3 of the equation text are theta, gamma, dtheta, dgamma: the `replacements` of :62)."""
+    import sympy as sp
+    # real=True only matters for Abs (its derivative is sign(x) for real x; the reference's plain symbols would leave an
+    # unevaluated Derivative(re(..)) there); every other operator differentiates identically
+    th, ga, dth, dga, ddth, ddga = sp.symbols("th ga dth dga ddth ddga", real=True)
+    L = sp.sympify(lagrangian, locals={"x0": th, "x1": ga, "x2": dth, "x3": dga, "square": lambda v: v ** 2, "neg": lambda v: -v})
+    out = []
+    for q, dq in ((th, dth), (ga, dga)):
+        p = sp.diff(L, dq)                                                       # :66 / :76
+        d_p = sp.diff(p, th) * dth + sp.diff(p, ga) * dga + sp.diff(p, dth) * ddth + sp.diff(p, dga) * ddga   # :68-71
+        out.append(d_p - sp.diff(L, q))                                          # :72
+    return out[0], out[1], (th, ga, dth, dga, ddth, ddga)
+
+
+def el_residuals(lagrangian: str, theta, gamma, dtheta, dgamma, ddtheta, ddgamma):
+    """`evaluate` of lagrangian_pipeline_old.py:85-90: the two residual series."""
+    import sympy as sp
+    e_th, e_ga, syms = el_equations(lagrangian)
+    args = [np.asarray(v, float) for v in (theta, gamma, dtheta, dgamma, ddtheta, ddgamma)]
+    f_th = sp.lambdify(syms, e_th, modules="numpy"); f_ga = sp.lambdify(syms, e_ga, modules="numpy")
+    z = np.zeros_like(args[0])
+    return np.asarray(f_th(*args), float) + z, np.asarray(f_ga(*args), float) + z
+
+
+def lagrangian_accelerations(lagrangian: str):
+    """(ddtheta(th, ga, dth, dga), ddgamma(...)) callables: sp.solve(EOM, ddq)[0] of lagrangian_pipeline.py:146-171."""
+    import sympy as sp
+    e_th, e_ga, (th, ga, dth, dga, ddth, ddga) = el_equations(lagrangian)
+    s_th = sp.solve(e_th, ddth)[0]; s_ga = sp.solve(e_ga, ddga)[0]
+    return (sp.lambdify([th, ga, dth, dga], s_th, modules="numpy"), sp.lambdify([th, ga, dth, dga], s_ga, modules="numpy"))
+
+
+def lagrangian_rollout(acc_theta, acc_gamma, time, theta0, gamma0, vtheta0, vgamma0):
+    """evaluate_lagrangian_on_test.py:59-68, statement by statement."""
+    T = len(time)
+    theta_est = np.zeros(T); gamma_est = np.zeros(T); vtheta = np.zeros(T); vgamma = np.zeros(T)
+    theta_est[0], gamma_est[0], vtheta[0], vgamma[0] = theta0, gamma0, vtheta0, vgamma0
+    for i in range(1, T):
+        dt = time[i] - time[i - 1]
+        a_th = acc_theta(theta_est[i - 1], gamma_est[i - 1], vtheta[i - 1], vgamma[i - 1])
+        a_ga = acc_gamma(theta_est[i - 1], gamma_est[i - 1], vtheta[i - 1], vgamma[i - 1])
+        vtheta[i] = vtheta[i - 1] + a_th * dt
+        theta_est[i] = theta_est[i - 1] + vtheta[i - 1] * dt
+        vgamma[i] = vgamma[i - 1] + a_ga * dt
+        gamma_est[i] = gamma_est[i - 1] + vgamma[i - 1] * dt
+    return theta_est, gamma_est, vtheta, vgamma

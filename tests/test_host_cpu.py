@@ -264,3 +264,44 @@ def test_generation3_model_compiles_named_variables():
     assert "x1" in rovmpc.disassemble(m2.prog_gamma, m2.consts)
     with pytest.raises(rovmpc.ExpressionError):
         rovmpc.DynamicsModel(np.zeros(14), np.ones(14), "gamma_typo*2", "theta", variable_names=rovmpc.FEATURE_NAMES_GEN3)
+
+
+# ---- Euler-Lagrange front end (host symbolic part; the numeric part is GPU) ---------------------------------------------
+
+def _np_eval(text, X):
+    ns = {f"x{i}": X[:, i] for i in range(X.shape[1])}
+    ns.update(sin=np.sin, cos=np.cos, tanh=np.tanh, exp=np.exp, log=np.log, sqrt=np.sqrt, abs=np.abs, Abs=np.abs,
+              square=lambda v: v * v, neg=lambda v: -v)
+    return eval(text, {"__builtins__": {}}, ns) + np.zeros(X.shape[0])
+
+
+def test_euler_lagrange_derivation_matches_the_reference_route():
+    """rovmpc.euler_lagrange (own differentiation on the expression tree, no computer algebra in the product) against the
+    residuals sympy produces the reference's way (golden: reference-held files + synthetic Lagrangians)."""
+    import rovmpc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kat_lagrangian.npz"))
+    traj = np.column_stack([g[k] for k in ("theta", "gamma", "dtheta", "dgamma", "ddtheta", "ddgamma")])
+    for tag in ("full", "split_hy", "split"):
+        el = rovmpc.euler_lagrange(str(g[f"expr_{tag}"]))
+        np.testing.assert_allclose(_np_eval(el.eom_theta, traj), g[f"residual_theta_{tag}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(_np_eval(el.eom_gamma, traj), g[f"residual_gamma_{tag}"], rtol=1e-12, atol=1e-13)
+    el = rovmpc.euler_lagrange(str(g["expr_full"]))
+    assert el.eom_theta == "2.0 * x4" and el.eom_gamma == "2.0 * x5" and el.acc_theta == "0.0"
+    rows = g["synth_rows"]
+    for j, txt in enumerate(g["synth_exprs"]):
+        el = rovmpc.euler_lagrange(str(txt))
+        np.testing.assert_allclose(_np_eval(el.eom_theta, rows), g[f"synth_res_theta_{j}"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(_np_eval(el.eom_gamma, rows), g[f"synth_res_gamma_{j}"], rtol=1e-10, atol=1e-12)
+        assert el.acc_theta is not None and el.acc_gamma is not None
+    # a dtheta*dgamma term couples the accelerations: sp.solve(EOM_theta, ddtheta)[0] keeps ddgamma, which the reference's
+    # lambdify over (theta, gamma, dtheta, dgamma) cannot evaluate -- reported as not isolable; so is a missing d^2 term
+    el = rovmpc.euler_lagrange("0.5*x2**2 + 0.5*x3**2 + 0.3*x2*x3*cos(x0) - x0**2")
+    assert el.acc_theta is None and el.acc_gamma is None and "x5" in el.eom_theta and "x4" in el.eom_gamma
+    assert rovmpc.euler_lagrange("x0*x2 + 0.5*x3**2").acc_theta is None
+    # named variables, and what the grammar refuses
+    el = rovmpc.euler_lagrange("0.5*dth**2 + 0.5*dga**2 - th*ga", variable_names=("th", "ga", "dth", "dga"))
+    assert el.eom_theta == "x4 + x1" and el.acc_gamma == "-x0"
+    with pytest.raises(rovmpc.ExpressionError):
+        rovmpc.euler_lagrange("x2**2 + x7")
+    with pytest.raises(rovmpc.ExpressionError):
+        rovmpc.euler_lagrange("x2**x0")

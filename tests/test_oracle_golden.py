@@ -335,3 +335,17 @@ def test_philox_restatement_known_answers():
     U = orc.sample_candidates(7, 3, 5, 4, [1.0, 2.0, 3.0], [0.5, 0.25, 2.0], prev_best=np.arange(12.0).reshape(4, 3))
     assert np.array_equal(U[0], np.array([[3, 4, 5], [6, 7, 8], [9, 10, 11], [9, 10, 11]], float))
     assert np.allclose(U[1, 0], np.array([1.0, 2.0, 3.0]) + np.array([0.5, 0.25, 2.0]) * z[12:15])
+
+
+def test_lagrangian_oracle_reproduces_the_reference_residual_files(golden_dir):
+    """oracle.el_residuals (sympy, the reference's route) against the residual series the reference's own Lagrangian runs
+    stored (outputs/Lg_C6_*/euler_lagrange_residuals.npz on trajectory_data.npz), incl. the two split runs whose T - V
+    cancels identically."""
+    from oracle import rovmpc_oracle as orc
+    g = np.load(os.path.join(golden_dir, "kat_lagrangian.npz"))
+    series = [g[k] for k in ("theta", "gamma", "dtheta", "dgamma", "ddtheta", "ddgamma")]
+    for tag in ("full", "split_hy", "split"):
+        r_th, r_ga = orc.el_residuals(str(g[f"expr_{tag}"]), *series)
+        np.testing.assert_allclose(r_th, g[f"residual_theta_{tag}"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(r_ga, g[f"residual_gamma_{tag}"], rtol=1e-12, atol=1e-15)
+    assert np.allclose(g["residual_theta_full"], 2 * g["ddtheta"])               # L = dtheta^2 + dgamma^2

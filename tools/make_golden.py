@@ -367,6 +367,48 @@ def main():
     tt, th_s, ga_s = main_fun.preprocess_signals(dfd, sigma=2)
     tt3, th_s3, ga_s3 = main_fun.preprocess_signals(dfd.iloc[:6], sigma=3.5)         # log shorter than the kernel radius
     ddt, ddg = main_fun.compute_derivatives(dfd)
+    # ---- Lagrangian evaluation: fixtures the reference itself holds (outputs of its Lagrangian runs: the trajectory the
+    # residuals were evaluated on, the residual series, the expression texts), plus synthetic Lagrangians through the
+    # reference's route (sympy diff / solve / lambdify, restated in the oracle) --------------------------------------------
+    from oracle import rovmpc_oracle as orc_l
+    lag = {}
+    for tag, run in (("full", "Lg_C6_full_1K_20250424_130306"), ("split_hy", "Lg_C6_split_Hy_1K_20it_20250424_165101"),
+                     ("split", "Lg_C6_split_1K_20it_20250424_151011")):
+        d = os.path.join(REF, "outputs", run)
+        tr = np.load(os.path.join(d, "trajectory_data.npz"), allow_pickle=False)
+        rs = np.load(os.path.join(d, "euler_lagrange_residuals.npz"), allow_pickle=False)
+        txt = open(os.path.join(d, "best_lagrangian.txt" if tag == "full" else "lagrangian_expression.txt")).read().strip()
+        for k in ("theta", "gamma", "dtheta", "dgamma", "ddtheta", "ddgamma", "time"):
+            if tag == "full":
+                lag[k] = tr[k]
+            else:
+                assert np.array_equal(tr[k], lag[k])                  # the three runs share one training trajectory
+        lag[f"expr_{tag}"] = np.array(txt)
+        lag[f"residual_theta_{tag}"] = rs["residual_theta"].astype(np.float64)
+        lag[f"residual_gamma_{tag}"] = rs["residual_gamma"].astype(np.float64)
+        # the oracle's restatement reproduces the reference's stored residuals
+        r_th, r_ga = orc_l.el_residuals(txt, *(lag[k] for k in ("theta", "gamma", "dtheta", "dgamma", "ddtheta", "ddgamma")))
+        assert np.allclose(r_th, lag[f"residual_theta_{tag}"], rtol=1e-12, atol=1e-15), tag
+        assert np.allclose(r_ga, lag[f"residual_gamma_{tag}"], rtol=1e-12, atol=1e-15), tag
+    synth = ["0.5*x2**2 + 0.5*sin(x0)**2*x3**2 + 9.81*cos(x0) - 0.3*x1**2",
+             "x2**2*(1.0 + 0.2*cos(x1)) + 0.7*x3**2*exp(-x0**2) - tanh(x0*x1) - 0.5*x1**2",
+             "(x2*x2 + x3*x3)*sqrt(1.5 + x0*x0) - Abs(x0) - square(x1) + x0*x3/(2.0 + x1*x1)"]
+    rs_ = np.random.default_rng(77)
+    rows = rs_.normal(0.0, 0.6, size=(300, 6))
+    lag["synth_rows"] = rows
+    lag["synth_exprs"] = np.array(synth)
+    tsyn = np.cumsum(np.r_[0.0, rs_.uniform(0.004, 0.012, 199)])
+    lag["synth_time"] = tsyn
+    y0s = rs_.normal(0.0, 0.3, size=(5, 4))
+    lag["synth_y0"] = y0s
+    for j, txt in enumerate(synth):
+        r_th, r_ga = orc_l.el_residuals(txt, *rows.T)
+        lag[f"synth_res_theta_{j}"] = r_th; lag[f"synth_res_gamma_{j}"] = r_ga
+        if j < 2:                                                    # the third couples ddtheta and ddgamma: not isolable
+            f_th, f_ga = orc_l.lagrangian_accelerations(txt)
+            lag[f"synth_rollout_{j}"] = np.array([orc_l.lagrangian_rollout(f_th, f_ga, tsyn, *y) for y in y0s])   # (5, 4, T)
+    np.savez(f"{OUT}/kat_lagrangian.npz", **lag)
+
     np.savez(f"{OUT}/kat_smoothing.npz", theta_gauss2=th_s, gamma_gauss2=ga_s, theta_gauss35_first6=th_s3, gamma_gauss35_first6=ga_s3,
              ddtheta=ddt, ddgamma=ddg)
 
