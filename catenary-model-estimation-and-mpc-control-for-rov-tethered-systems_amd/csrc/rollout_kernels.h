@@ -336,20 +336,36 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
 
 // LDS plane addressing: plane p, node n (0..N), lane c (0..CK-1); c fastest => conflict-free.
 #define RV_PL(base, p, n, c) (base)[((p) * (N + 1) + (n)) * CK + (c)]
+// exogenous feature plane s (0..13): a hiprtc-specialised kernel keeps only the planes its expressions read, packed
+// (xpl(s) = number of used planes below s, a literal after unrolling); the other variants keep plane s at s
+#define RV_PX(s, n, c) RV_PL(sX, xpl(s), n, c)
 
 // Node planes kept in LDS.  The compiled-in model reads only x3 (and x14..x17, which are
 // state), so its workgroups keep P (3), theta/gamma (2) and either the x3 plane or the five
 // rotation-axis components; the interpreter keeps the whole scaled exogenous row.
-__host__ __device__ inline int rollout_nx(int model, int vt) {
-    return model == MODEL_BUILTIN ? (vt == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
+__host__ __device__ inline int popcount14(unsigned used) {
+    int n = 0;
+    for (int s = 0; s < NEXO; ++s) n += (used >> s) & 1u;
+    return n;
+}
+// Planes a hiprtc-specialised kernel keeps in LDS: the used ones, minus -- under VT_COMPOSE -- those that hang on the
+// velocity (planes 3..8 and 13 of generations 1/2, every plane of generation 3): only the integrating lane reads them,
+// from registers (integrate_jit / integrate_dd_jit).
+__host__ __device__ inline unsigned jit_lds_planes(unsigned used, int vt, int fmap) {
+    if (vt != ROVMPC_VT_COMPOSE) return used;
+    return fmap == ROVMPC_FEATURES_GEN3 ? 0u : used & ~0x21f8u;
+}
+__host__ __device__ inline int rollout_nx(int model, int vt, unsigned used = 0xffffffffu) {
+    if (model == MODEL_BUILTIN) return vt == ROVMPC_VT_COMPOSE ? 0 : 1;
+    return model == MODEL_JIT ? (popcount14(used) > 0 ? popcount14(used) : 1) : NEXO;
 }
 __host__ __device__ inline int rollout_na(int model, int vt) {
     return vt == ROVMPC_VT_COMPOSE ? NAX : 5;   // axes are reused by phase 4b; compose: + 3 (unit_rel, or w of the compiled-in path)
 }
 constexpr int HDR = 48;            // header: flags (8 slots) + mean[18] + inv_scale[18] (+ pad)
 
-template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt) {
-    size_t planes = 3 /*P*/ + 2 /*theta,gamma*/ + rollout_nx(model, vt) + rollout_na(model, vt);
+template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt, unsigned used = 0xffffffffu) {
+    size_t planes = 3 /*P*/ + 2 /*theta,gamma*/ + rollout_nx(model, vt, used) + rollout_na(model, vt);
     size_t e = HDR;
     e += planes * (size_t)(N + 1) * CK;              // node planes
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
@@ -385,7 +401,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int prob = blockIdx.y;
     const T *Ub = a.U + (size_t)prob * K * N * 3;
     const int nvalid = min(CK, K - k0);
-    constexpr int NX = MODEL == MODEL_BUILTIN ? (VT == ROVMPC_VT_COMPOSE ? 0 : 1) : NEXO;
+    const unsigned used_lds = MODEL == MODEL_JIT ? jit_lds_planes(used, VT, fmap) : used;
+    const int NX = rollout_nx(MODEL, VT, used_lds);
+    auto xpl = [&](int s) { return MODEL == MODEL_JIT ? popcount14(used_lds & ((1u << s) - 1u)) : s; };
     constexpr int NA = VT == ROVMPC_VT_COMPOSE ? NAX : 5;
 
     // carve LDS
@@ -581,7 +599,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 T Vx, Vy, Vz;
                 vel(c, n, Vx, Vy, Vz);
                 const T x3 = (Vx - sMean[3]) * sInv[3];                      // x3 is all the model reads
-                RV_PL(sX, 0, n, c) = x3;
+                RV_PX(0, n, c) = x3;
                 if (!Trig<T>::bounded(m_abs(x3))) s_prog[0] = 1;             // a sine argument of the theta chain is huge (or NaN)
             }
             continue;
@@ -620,17 +638,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T row[10] = {sway_n, surge_n, a_sway, a_surge, kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, kk.vs * Ax, kk.vs * Ay, kk.vs * Az};
 #pragma unroll
             for (int p = 0; p < 10; ++p)
-                if (uses(p)) RV_PL(sX, p, n, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
+                if (uses(p)) RV_PX(p, n, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
             continue;
         }
         const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
-        if (uses(0)) RV_PL(sX, 0, n, c) = (Px - sMean[0]) * sInv[0];
-        if (uses(1)) RV_PL(sX, 1, n, c) = (Py - sMean[1]) * sInv[1];
-        if (uses(2)) RV_PL(sX, 2, n, c) = (Pz - sMean[2]) * sInv[2];
-        if (uses(9)) RV_PL(sX, 9, n, c) = (ux - sMean[9]) * sInv[9];
-        if (uses(10)) RV_PL(sX, 10, n, c) = (uy - sMean[10]) * sInv[10];
-        if (uses(11)) RV_PL(sX, 11, n, c) = (uz - sMean[11]) * sInv[11];
-        if (uses(12)) RV_PL(sX, 12, n, c) = (tension - sMean[12]) * sInv[12];
+        if (uses(0)) RV_PX(0, n, c) = (Px - sMean[0]) * sInv[0];
+        if (uses(1)) RV_PX(1, n, c) = (Py - sMean[1]) * sInv[1];
+        if (uses(2)) RV_PX(2, n, c) = (Pz - sMean[2]) * sInv[2];
+        if (uses(9)) RV_PX(9, n, c) = (ux - sMean[9]) * sInv[9];
+        if (uses(10)) RV_PX(10, n, c) = (uy - sMean[10]) * sInv[10];
+        if (uses(11)) RV_PX(11, n, c) = (uz - sMean[11]) * sInv[11];
+        if (uses(12)) RV_PX(12, n, c) = (tension - sMean[12]) * sInv[12];
         if (VT == ROVMPC_VT_COMPOSE) {
             RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
         } else {
@@ -644,13 +662,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T ap = (Vx * ux + Vy * uy + Vz * uz) / nv;
             const int apslot = fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
             if (fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
-            if (uses(3)) RV_PL(sX, 3, n, c) = (Vx - sMean[3]) * sInv[3];
-            if (uses(4)) RV_PL(sX, 4, n, c) = (Vy - sMean[4]) * sInv[4];
-            if (uses(5)) RV_PL(sX, 5, n, c) = (Vz - sMean[5]) * sInv[5];
-            if (uses(6)) RV_PL(sX, 6, n, c) = (Ax - sMean[6]) * sInv[6];
-            if (uses(7)) RV_PL(sX, 7, n, c) = (Ay - sMean[7]) * sInv[7];
-            if (uses(8)) RV_PL(sX, 8, n, c) = (Az - sMean[8]) * sInv[8];
-            if (uses(13)) RV_PL(sX, 13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
+            if (uses(3)) RV_PX(3, n, c) = (Vx - sMean[3]) * sInv[3];
+            if (uses(4)) RV_PX(4, n, c) = (Vy - sMean[4]) * sInv[4];
+            if (uses(5)) RV_PX(5, n, c) = (Vz - sMean[5]) * sInv[5];
+            if (uses(6)) RV_PX(6, n, c) = (Ax - sMean[6]) * sInv[6];
+            if (uses(7)) RV_PX(7, n, c) = (Ay - sMean[7]) * sInv[7];
+            if (uses(8)) RV_PX(8, n, c) = (Az - sMean[8]) * sInv[8];
+            if (uses(13)) RV_PX(13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
         }
     }
     RV_STAMP(12);
@@ -739,6 +757,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const int r = (N * CK) % 256;
         if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
     }
+    // (hiprtc-specialised models: one integrating wave, the others on the geometry; same early batch, taken by the first
+    // geometry wave while the integration runs)
+    if (MODEL == MODEL_JIT && CK <= 64 && NT >= 64 + 64 && N * CK > 256) {
+        const int r = (N * CK) % 256;
+        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
+    }
     // Measured and rejected: letting the geometry waves chase the integrating wave node by node
     // (LDS progress flags) -- a phase-4b item is a ~4 us dependent chain whatever the lane count, so
     // the tail after the last integration step does not shrink and the extra waves slow the
@@ -782,7 +806,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T opA = T(0), opB = T(0), opC = T(0), G = T(0);
             auto fetch = [&](int n) {
                 if (VT == ROVMPC_VT_COMPOSE) { opA = RV_PL(sA, 5, n, c); opB = RV_PL(sA, 6, n, c); opC = RV_PL(sA, 7, n, c); }
-                else opB = RV_PL(sX, 0, n + 1, c);
+                else opB = RV_PX(0, n + 1, c);
                 G = sG[8 * n + 2];
             };
             if (nsteps > 0) fetch(0);
@@ -903,14 +927,14 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     T ap = (vx * ux + vy * uy + vz * uz) / nv;
                     const int apslot = gen2 ? 16 : 13;
                     if (!gen2) ap = m_clip(ap, T(-1), T(1));
-                    RV_PL(sX, 13, node, c) = (ap - sMean[apslot]) * sInv[apslot];
+                    RV_PX(13, node, c) = (ap - sMean[apslot]) * sInv[apslot];
                 }
-                if (uses(3)) RV_PL(sX, 3, node, c) = (vx - sMean[3]) * sInv[3];
-                if (uses(4)) RV_PL(sX, 4, node, c) = (vy - sMean[4]) * sInv[4];
-                if (uses(5)) RV_PL(sX, 5, node, c) = (vz - sMean[5]) * sInv[5];
-                if (uses(6)) RV_PL(sX, 6, node, c) = (ax - sMean[6]) * sInv[6];
-                if (uses(7)) RV_PL(sX, 7, node, c) = (ay - sMean[7]) * sInv[7];
-                if (uses(8)) RV_PL(sX, 8, node, c) = (az - sMean[8]) * sInv[8];
+                if (uses(3)) RV_PX(3, node, c) = (vx - sMean[3]) * sInv[3];
+                if (uses(4)) RV_PX(4, node, c) = (vy - sMean[4]) * sInv[4];
+                if (uses(5)) RV_PX(5, node, c) = (vz - sMean[5]) * sInv[5];
+                if (uses(6)) RV_PX(6, node, c) = (ax - sMean[6]) * sInv[6];
+                if (uses(7)) RV_PX(7, node, c) = (ay - sMean[7]) * sInv[7];
+                if (uses(8)) RV_PX(8, node, c) = (az - sMean[8]) * sInv[8];
             };
             const bool vel_used = (used & 0x21f8u) != 0;     // planes 3..8, 13
             if (VT == ROVMPC_VT_COMPOSE && vel_used) store_vslots(0, Vx, Vy, Vz, A0x, A0y, A0z);
@@ -941,9 +965,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         T x[18];
 #pragma unroll
                         for (int s = 0; s < NEXO; ++s) {
-                            if (cfrac2 == 0) x[s] = RV_PL(sX, s, n, c);
-                            else if (cfrac2 == 2) x[s] = RV_PL(sX, s, n + 1, c);
-                            else x[s] = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);   // :62
+                            if (cfrac2 == 0) x[s] = RV_PX(s, n, c);
+                            else if (cfrac2 == 2) x[s] = RV_PX(s, n + 1, c);
+                            else x[s] = (RV_PX(s, n, c) + RV_PX(s, n + 1, c)) / T(2);   // :62
                         }
                         if (gen2) {
                             // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
@@ -961,9 +985,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     for (int s = 0; s < NEXO; ++s) {
                         if (!uses(s)) continue;
                         T v;
-                        if (cfrac2 == 0) v = RV_PL(sX, s, n, c);
-                        else if (cfrac2 == 2) v = RV_PL(sX, s, n + 1, c);
-                        else v = (RV_PL(sX, s, n, c) + RV_PL(sX, s, n + 1, c)) / T(2);      // :62
+                        if (cfrac2 == 0) v = RV_PX(s, n, c);
+                        else if (cfrac2 == 2) v = RV_PX(s, n + 1, c);
+                        else v = (RV_PX(s, n, c) + RV_PX(s, n + 1, c)) / T(2);      // :62
                         feat[s * CK] = v;
                     }
                     if (gen2) {
@@ -1015,7 +1039,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 const T row[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
 #pragma unroll
                 for (int p = 0; p < 10; ++p)
-                    if (uses(p)) RV_PL(sX, p, node, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
+                    if (uses(p)) RV_PX(p, node, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
             };
             T *feat = sF + c;
             T *stack = sF + 18 * CK + c;
@@ -1041,9 +1065,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         T x[18];
 #pragma unroll
                         for (int p = 0; p < 10; ++p) {
-                            if (cfrac2 == 0) x[4 + p] = RV_PL(sX, p, n, c);
-                            else if (cfrac2 == 2) x[4 + p] = RV_PL(sX, p, n + 1, c);
-                            else x[4 + p] = (RV_PL(sX, p, n, c) + RV_PL(sX, p, n + 1, c)) / T(2);
+                            if (cfrac2 == 0) x[4 + p] = RV_PX(p, n, c);
+                            else if (cfrac2 == 2) x[4 + p] = RV_PX(p, n + 1, c);
+                            else x[4 + p] = (RV_PX(p, n, c) + RV_PX(p, n + 1, c)) / T(2);
                         }
                         x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                         x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
@@ -1055,9 +1079,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     for (int p = 0; p < 10; ++p) {
                         if (!uses(p)) continue;
                         T v;
-                        if (cfrac2 == 0) v = RV_PL(sX, p, n, c);
-                        else if (cfrac2 == 2) v = RV_PL(sX, p, n + 1, c);
-                        else v = (RV_PL(sX, p, n, c) + RV_PL(sX, p, n + 1, c)) / T(2);
+                        if (cfrac2 == 0) v = RV_PX(p, n, c);
+                        else if (cfrac2 == 2) v = RV_PX(p, n + 1, c);
+                        else v = (RV_PX(p, n, c) + RV_PX(p, n + 1, c)) / T(2);
                         feat[(4 + p) * CK] = v;
                     }
                     feat[0] = (s0 - sMean[0]) * sInv[0]; feat[CK] = (s1 - sMean[1]) * sInv[1];
@@ -1089,9 +1113,275 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
             }
         };
+
+        // ---- hiprtc-specialised models: the same integration with the per-step instruction chain cut down -------------
+        // (measured at C2: generation 2 rows 58.6 -> see profiles/r02_other_configs.jsonl).  What changes against the
+        // loop above, none of it in the arithmetic of a stage:
+        //  * the exogenous rows of the two step ends live in registers (xa, xb); the velocity-dependent slots, which
+        //    only this lane ever reads, never go through LDS (no store -> load round trip on the chain, and no LDS
+        //    planes for them);
+        //  * the operands of step n + 1 (axes, control, unit vector, state-independent rows) are fetched during step n;
+        //  * sincos(theta_n), sincos(gamma_n) -- velocity transform, generation-2 slots cos(theta) / sin(gamma) at the
+        //    stage states -- advance by the angle-addition formulas from the previous evaluation (odd / even Taylor
+        //    polynomials of the increment to d^7 / d^8, truncation < 5e-17 for |d| < 2^-7), re-anchored by a full
+        //    evaluation every 16 steps and for any lane whose increment is larger (wave-uniform choice, per-lane
+        //    result: a candidate's arithmetic never depends on its neighbours).
+        auto add_angle = [](T s0, T c0, T d, T &s, T &c) {
+            const T d2 = d * d;
+            const T sd = d * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+            const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
+            s = s0 * cd + c0 * sd; c = c0 * cd - s0 * sd;
+        };
+        auto sincos_near = [&](T x, T xanchor, T sa, T ca, T &s, T &c) {
+            const T d = x - xanchor;
+            const bool big = !(m_abs(d) < T(0.0078125));
+            T rs, rc;
+            add_angle(sa, ca, d, rs, rc);
+            if (__any(big)) {                       // rare: some lane of the wave moved by more than 2^-7
+                T fs, fc;
+                m_sincos(x, &fs, &fc);
+                if (big) { rs = fs; rc = fc; }
+            }
+            s = rs; c = rc;
+        };
+        constexpr unsigned VELMASK = 0x21f8u;       // planes 3..8 and 13: velocity, acceleration, angle_proj
+        auto integrate_jit = [&]() {
+            if (tid >= CK) return;
+            const int c = tid;
+            const int nsteps = (a.debug & 1) ? 0 : N;
+            T th = th0, ga = ga0, thm = thm0, gam = gam0;
+            RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
+            const T m14 = sMean[14], i14 = sInv[14], m15 = sMean[15], i15 = sInv[15];
+            const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
+            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+            const bool euler = a.integrator == ROVMPC_EULER;
+            const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * hstep, h6 = hstep / T(6);
+            const bool gen2 = fmap == ROVMPC_FEATURES_GEN2;
+            const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & VELMASK) != 0;
+            auto in_lds = [&](int sl) { return uses(sl) && !(VT == ROVMPC_VT_COMPOSE && ((VELMASK >> sl) & 1u)); };
+            const int apslot = gen2 ? 16 : 13;
+            T xa[NEXO], xb[NEXO], xn[NEXO];
+#pragma unroll
+            for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl] = xn[sl] = T(0); if (in_lds(sl)) xa[sl] = RV_PX(sl, 0, c); }
+            // velocity-dependent slots of one node from (v, a, unit vector): simply.py:29-31, scaled
+            auto vel_slots = [&](T *x, T vx, T vy, T vz, T ax, T ay, T az, T ux, T uy, T uz) {
+                if (uses(13)) {
+                    const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
+                    T ap = (vx * ux + vy * uy + vz * uz) / nv;
+                    if (!gen2) ap = m_clip(ap, T(-1), T(1));
+                    x[13] = (ap - sMean[apslot]) * sInv[apslot];
+                }
+                if (uses(3)) x[3] = (vx - sMean[3]) * sInv[3];
+                if (uses(4)) x[4] = (vy - sMean[4]) * sInv[4];
+                if (uses(5)) x[5] = (vz - sMean[5]) * sInv[5];
+                if (uses(6)) x[6] = (ax - sMean[6]) * sInv[6];
+                if (uses(7)) x[7] = (ay - sMean[7]) * sInv[7];
+                if (uses(8)) x[8] = (az - sMean[8]) * sInv[8];
+            };
+            T Vx = V0x, Vy = V0y, Vz = V0z;
+            if (compose_rows)
+                vel_slots(xa, Vx, Vy, Vz, A0x, A0y, A0z, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c));
+            // operands of a step: rotation axes and control of node n, unit vector of node n + 1
+            T o_ktx = T(0), o_kty = T(0), o_kgx = T(0), o_kgy = T(0), o_kgz = T(0), o_u0 = T(0), o_u1 = T(0), o_u2 = T(0), o_ux = T(0), o_uy = T(0), o_uz = T(0);
+            T p_ktx = T(0), p_kty = T(0), p_kgx = T(0), p_kgy = T(0), p_kgz = T(0), p_u0 = T(0), p_u1 = T(0), p_u2 = T(0), p_ux = T(0), p_uy = T(0), p_uz = T(0);
+            auto fetch_ops = [&](int n) {
+                if (!compose_rows) return;
+                p_ktx = RV_PL(sA, 0, n, c); p_kty = RV_PL(sA, 1, n, c);
+                p_kgx = RV_PL(sA, 2, n, c); p_kgy = RV_PL(sA, 3, n, c); p_kgz = RV_PL(sA, 4, n, c);
+                const T *u = &sU[c * US + n * 3];
+                p_u0 = u[0]; p_u1 = u[1]; p_u2 = u[2];
+                if (uses(13)) { p_ux = RV_PL(sA, 5, n + 1, c); p_uy = RV_PL(sA, 6, n + 1, c); p_uz = RV_PL(sA, 7, n + 1, c); }
+            };
+            auto take_ops = [&]() {
+                o_ktx = p_ktx; o_kty = p_kty; o_kgx = p_kgx; o_kgy = p_kgy; o_kgz = p_kgz;
+                o_u0 = p_u0; o_u1 = p_u1; o_u2 = p_u2; o_ux = p_ux; o_uy = p_uy; o_uz = p_uz;
+            };
+            auto fetch_rows = [&](int node, T *x) {
+#pragma unroll
+                for (int sl = 0; sl < NEXO; ++sl) if (in_lds(sl)) x[sl] = RV_PX(sl, node, c);
+            };
+            if (nsteps > 0) { fetch_ops(0); take_ops(); fetch_rows(1, xb); }
+            // sincos of the node state (velocity transform; anchor of the generation-2 slots)
+            const bool need_trig = compose_rows || gen2;
+            T st = T(0), ct = T(1), sg = T(0), cg = T(1);
+            if (need_trig) { m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg); }
+            for (int n = 0; n < nsteps; ++n) {
+                if (n + 1 < nsteps) { fetch_ops(n + 1); fetch_rows(n + 2, xn); }
+                if (compose_rows) {
+                    const V3<T> kt = {o_ktx, o_kty, T(0)}, kg = {o_kgx, o_kgy, o_kgz};
+                    V3<T> v = rodrigues_unit<T>({o_u0, o_u1, o_u2}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    vel_slots(xb, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o_ux, o_uy, o_uz);
+                    Vx = v.x; Vy = v.y; Vz = v.z;
+                }
+                const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
+                const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;
+                auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
+                    T p16, p17;
+                    if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
+                    else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
+                    else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
+                    T x[18];
+#pragma unroll
+                    for (int sl = 0; sl < NEXO; ++sl)
+                        x[sl] = cfrac2 == 0 ? xa[sl] : (cfrac2 == 2 ? xb[sl] : (xa[sl] + xb[sl]) / T(2));   // :62
+                    if (gen2) {
+                        // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
+                        x[16] = x[13];
+                        x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
+                        T s_t, c_t, s_g, c_g;
+                        sincos_near(yth, th, st, ct, s_t, c_t);
+                        sincos_near(yga, ga, sg, cg, s_g, c_g);
+                        x[14] = (c_t - m14) * i14; x[15] = (s_g - m15) * i15;
+                        x[17] = T(0);
+                    } else {
+                        x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
+                    }
+                    dth = jit_f_theta<T>(x);
+                    dga = jit_f_gamma<T>(x);
+                };
+                T k1t, k1g;
+                stage(th, ga, 0, k1t, k1g);
+                T thn, gan;
+                if (euler) {
+                    thn = th + k1t * hstep;                                     // main_fun.py:761
+                    gan = ga + k1g * hstep;
+                } else {
+                    T k2t, k2g, k3t, k3g, k4t, k4g;
+                    stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
+                    stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
+                    stage(th + hstep * k3t, ga + hstep * k3g, 2, k4t, k4g);
+                    thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
+                    gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
+                }
+                if (need_trig && n + 1 < nsteps) {
+                    if (((n + 1) & 15) == 0) { m_sincos(thn, &st, &ct); m_sincos(gan, &sg, &cg); }
+                    else { sincos_near(thn, th, st, ct, st, ct); sincos_near(gan, ga, sg, cg, sg, cg); }
+                }
+                thm = th; gam = ga; th = thn; ga = gan;
+                RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
+                // progress word for the early phase-4b batch (one wave's DS operations complete in order)
+                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl]; if (in_lds(sl)) xb[sl] = xn[sl]; }
+                take_ops();
+            }
+        };
+        // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
+        // VT_COMPOSE no row goes through LDS at all
+        auto integrate_dd_jit = [&]() {
+            if (tid >= CK) return;
+            const int c = tid;
+            const int nsteps = (a.debug & 1) ? 0 : N;
+            T y0 = th0, y1 = ga0, y2 = thm0, y3 = gam0;
+            RV_PL(sY, 0, 0, c) = y0; RV_PL(sY, 1, 0, c) = y1;
+            const bool euler = a.integrator == ROVMPC_EULER;
+            const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * kk.h, h6 = kk.h / T(6);
+            const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & 0x3ffu) != 0;
+            auto in_lds = [&](int p) { return uses(p) && VT != ROVMPC_VT_COMPOSE; };
+            T xa[10], xb[10], xn[10];
+#pragma unroll
+            for (int p = 0; p < 10; ++p) { xa[p] = xb[p] = xn[p] = T(0); if (in_lds(p)) xa[p] = RV_PX(p, 0, c); }
+            auto row = [&](T *x, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
+                const T r[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
+#pragma unroll
+                for (int p = 0; p < 10; ++p) if (uses(p)) x[p] = (r[p] - sMean[4 + p]) * sInv[4 + p];
+            };
+            T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
+            if (compose_rows)
+                dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
+            T o_ktx = T(0), o_kty = T(0), o_kgx = T(0), o_kgy = T(0), o_kgz = T(0), o_u0 = T(0), o_u1 = T(0), o_u2 = T(0), o_ux = T(0), o_uy = T(0), o_uz = T(0);
+            T p_ktx = T(0), p_kty = T(0), p_kgx = T(0), p_kgy = T(0), p_kgz = T(0), p_u0 = T(0), p_u1 = T(0), p_u2 = T(0), p_ux = T(0), p_uy = T(0), p_uz = T(0);
+            auto fetch_ops = [&](int n) {
+                if (!compose_rows) return;
+                p_ktx = RV_PL(sA, 0, n, c); p_kty = RV_PL(sA, 1, n, c);
+                p_kgx = RV_PL(sA, 2, n, c); p_kgy = RV_PL(sA, 3, n, c); p_kgz = RV_PL(sA, 4, n, c);
+                const T *u = &sU[c * US + n * 3];
+                p_u0 = u[0]; p_u1 = u[1]; p_u2 = u[2];
+                p_ux = RV_PL(sA, 5, n + 1, c); p_uy = RV_PL(sA, 6, n + 1, c); p_uz = RV_PL(sA, 7, n + 1, c);
+            };
+            auto take_ops = [&]() {
+                o_ktx = p_ktx; o_kty = p_kty; o_kgx = p_kgx; o_kgy = p_kgy; o_kgz = p_kgz;
+                o_u0 = p_u0; o_u1 = p_u1; o_u2 = p_u2; o_ux = p_ux; o_uy = p_uy; o_uz = p_uz;
+            };
+            auto fetch_rows = [&](int node, T *x) {
+#pragma unroll
+                for (int p = 0; p < 10; ++p) if (in_lds(p)) x[p] = RV_PX(p, node, c);
+            };
+            if (nsteps > 0) { fetch_ops(0); take_ops(); fetch_rows(1, xb); }
+            T st = T(0), ct = T(1), sg = T(0), cg = T(1);
+            if (compose_rows) { m_sincos(y0, &st, &ct); m_sincos(y1, &sg, &cg); }
+            for (int n = 0; n < nsteps; ++n) {
+                if (n + 1 < nsteps) { fetch_ops(n + 1); fetch_rows(n + 2, xn); }
+                if (compose_rows) {
+                    const V3<T> kt = {o_ktx, o_kty, T(0)}, kg = {o_kgx, o_kgy, o_kgz};
+                    V3<T> v = rodrigues_unit<T>({o_u0, o_u1, o_u2}, kg, -sg, cg);
+                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    T sway_n, surge_n;
+                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, o_ux, o_uy, o_uz, sway_n, surge_n);
+                    const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
+                    if (n == 0) row(xa, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);   // np.gradient's edge rule
+                    row(xb, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
+                        (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
+                    Vx = v.x; Vy = v.y; Vz = v.z; sway_p = sway_n; surge_p = surge_n;
+                }
+                auto stage = [&](T s0, T s1, T s2, T s3, int cfrac2, T &ddth, T &ddga) {
+                    T x[18];
+#pragma unroll
+                    for (int p = 0; p < 10; ++p)
+                        x[4 + p] = cfrac2 == 0 ? xa[p] : (cfrac2 == 2 ? xb[p] : (xa[p] + xb[p]) / T(2));
+                    x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
+                    x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
+                    x[14] = x[15] = x[16] = x[17] = T(0);
+                    ddth = jit_f_theta<T>(x);
+                    ddga = jit_f_gamma<T>(x);
+                };
+                T a1t, a1g;
+                stage(y0, y1, y2, y3, 0, a1t, a1g);
+                T n0, n1;
+                if (euler) {
+                    n0 = y0 + y2 * hstep; n1 = y1 + y3 * hstep;                      // test_cluster.py:125-129
+                    y2 = y2 + a1t * hstep; y3 = y3 + a1g * hstep;                    // :113-117
+                } else {
+                    const T r1t = y2, r1g = y3;
+                    const T r2t = y2 + hh * a1t, r2g = y3 + hh * a1g;
+                    T a2t, a2g, a3t, a3g, a4t, a4g;
+                    stage(y0 + hh * r1t, y1 + hh * r1g, r2t, r2g, 1, a2t, a2g);
+                    const T r3t = y2 + hh * a2t, r3g = y3 + hh * a2g;
+                    stage(y0 + hh * r2t, y1 + hh * r2g, r3t, r3g, 1, a3t, a3g);
+                    const T r4t = y2 + hstep * a3t, r4g = y3 + hstep * a3g;
+                    stage(y0 + hstep * r3t, y1 + hstep * r3g, r4t, r4g, 2, a4t, a4g);
+                    n0 = y0 + h6 * (r1t + T(2) * r2t + T(2) * r3t + r4t);
+                    n1 = y1 + h6 * (r1g + T(2) * r2g + T(2) * r3g + r4g);
+                    y2 = y2 + h6 * (a1t + T(2) * a2t + T(2) * a3t + a4t);
+                    y3 = y3 + h6 * (a1g + T(2) * a2g + T(2) * a3g + a4g);
+                }
+                if (compose_rows && n + 1 < nsteps) {
+                    if (((n + 1) & 15) == 0) { m_sincos(n0, &st, &ct); m_sincos(n1, &sg, &cg); }
+                    else { sincos_near(n0, y0, st, ct, st, ct); sincos_near(n1, y1, sg, cg, sg, cg); }
+                }
+                y0 = n0; y1 = n1;
+                RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
+                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int p = 0; p < 10; ++p) { xa[p] = xb[p]; if (in_lds(p)) xb[p] = xn[p]; }
+                take_ops();
+            }
+        };
         const bool wide = NT > nint;
-        if (tid < nint) { if (fmap == ROVMPC_FEATURES_GEN3) integrate_dd(); else integrate(); }
-        if (!wide || tid >= nint) geometry_a(-1, wide ? tid - nint : tid, wide ? NT - nint : NT, 0);
+        if (tid < nint) {
+            if (MODEL == MODEL_JIT) { if (fmap == ROVMPC_FEATURES_GEN3) integrate_dd_jit(); else integrate_jit(); }
+            else { if (fmap == ROVMPC_FEATURES_GEN3) integrate_dd(); else integrate(); }
+            if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (also when no step ran)
+        }
+        const int j = (wide && MODEL == MODEL_JIT) ? tid - nint : -1;
+        const bool own = j >= 0 && j < early && !(a.debug & 2);
+        if (!wide || tid >= nint) geometry_a(own ? j : -1, wide ? tid - nint : tid, wide ? NT - nint : NT, wide ? early : 0);
+        if (own) {
+            const int n = j >> cks;
+            while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
+            geometry_b_item(n, j & ckm);
+        }
     }
     __syncthreads();
 

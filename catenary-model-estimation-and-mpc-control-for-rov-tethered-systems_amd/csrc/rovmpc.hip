@@ -151,12 +151,12 @@ extern "C" const char *rovmpc_last_error(const rovmpc_handle *h) {
 
 extern "C" int32_t rovmpc_result_len(const rovmpc_handle *h) { return h ? 5 + 2 * (h->cfg.N + 1) : 0; }
 
-static size_t lds_need(const rovmpc_config *c, int ck, int model) {
-    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, model, c->vt_mode) * sizeof(double)
-                                  : rollout_lds_elems<float>(c->N, ck, model, c->vt_mode) * sizeof(float);
+static size_t lds_need(const rovmpc_config *c, int ck, int model, unsigned used = 0xffffffffu) {
+    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, model, c->vt_mode, used) * sizeof(double)
+                                  : rollout_lds_elems<float>(c->N, ck, model, c->vt_mode, used) * sizeof(float);
 }
 
-static int pick_ck(const rovmpc_config *c, int model) {
+static int pick_ck(const rovmpc_config *c, int model, unsigned used, int n_cu) {
     if (c->candidates_per_block > 0) return c->candidates_per_block;
     // 16 candidates x 4 role lanes fill one wave in the sequential phase of the compiled-in
     // model; shrink only to keep two workgroups per CU inside the 160 KiB of LDS
@@ -164,8 +164,11 @@ static int pick_ck(const rovmpc_config *c, int model) {
     // large candidate sets: bigger workgroups (up to 64 candidates = four integrating waves, one
     // per SIMD) keep about one workgroup per CU instead of queueing several rounds of small ones
     while (ck < 64 && c->K / (ck * 2) >= 256) ck *= 2;
-    const size_t cap = ck > 16 ? 160 * 1024 : 64 * 1024;
-    while (ck > 1 && lds_need(c, ck, model) > cap) ck /= 2;
+    // up to one 16-candidate workgroup per CU a workgroup may take the CU's whole LDS (two workgroups sharing a CU put
+    // their integrating waves in each other's way: measured +25 % on the slower of the two); beyond that keep two per CU
+    const bool one_per_cu = (c->K + ck - 1) / ck <= n_cu;
+    const size_t cap = (ck > 16 || one_per_cu) ? 160 * 1024 : 80 * 1024;
+    while (ck > 1 && lds_need(c, ck, model, used) > cap) ck /= 2;
     return ck;
 }
 
@@ -229,15 +232,15 @@ static bool throughput_geometry(const rovmpc_handle *h, int n_cu, long long cand
 // interpreter's LDS layout cannot hold is not an error until a model that needs it is set.
 static const char *configure_geometry(rovmpc_handle *h, int model, bool strict = true) {
     const rovmpc_config *cfg = &h->cfg;
-    h->CK = pick_ck(cfg, model);
-    // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
-    // the per-node geometry phase is a single round
-    int items = cfg->N * h->CK;
-    h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
     if (strict) {
         hipDeviceProp_t prop{};
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
+    h->CK = pick_ck(cfg, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu, h->n_cu);
+    // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
+    // the per-node geometry phase is a single round
+    int items = cfg->N * h->CK;
+    h->NT = items >= 512 ? 512 : ((items + 63) / 64) * 64;
     if (strict && model == MODEL_BUILTIN && cfg->candidates_per_block == 0 && cfg->threads_per_block == 0) {
         int ck = 0, nt = 0;
         if (throughput_geometry(h, h->n_cu, cfg->K, &ck, &nt)) { h->CK = ck; h->NT = nt; }
@@ -245,7 +248,7 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     if (cfg->threads_per_block > 0) h->NT = cfg->threads_per_block;
     if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
-    if (strict && lds_need(cfg, h->CK, model) > 160 * 1024)
+    if (strict && lds_need(cfg, h->CK, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu) > 160 * 1024)
         return "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
     return nullptr;
 }
@@ -455,8 +458,12 @@ static hipFunction_t jit_build(int device, const std::string &src, std::string &
     const char *hdr_name[] = {"rovmpc.h", "device_math.h", "rollout_kernels.h"};
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "rovmpc_jit.hip", 3, hdr_src, hdr_name);
     if (r != HIPRTC_SUCCESS) { why = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(r); return nullptr; }
+#ifdef ROVMPC_STAMPS
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DROVMPC_JIT_BUILD=1", "-DROVMPC_STAMPS=1"};   // diagnostic library
+#else
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DROVMPC_JIT_BUILD=1"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+#endif
+    r = hiprtcCompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -738,7 +745,8 @@ template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h,
     a.result = d_result; a.k_offset = k_offset; a.slots = d_slots; a.rank = rank; a.world = world;
     const int vt = h->cfg.vt_mode;
     if (h->model_kind == MODEL_JIT) {
-        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt) * sizeof(T);
+        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         size_t asz = sizeof(a);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
         return hipModuleLaunchKernel(h->jit_fn, a.nblocks, B, 1, a.NT, 1, 1, (unsigned)lds, s, nullptr, extra);
@@ -1738,7 +1746,8 @@ static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64
     int capacity = 1 << 30;
     if (h->model_kind == MODEL_JIT) {
         if (!h->jit_fn_loop) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the run-time specialised module has no persistent entry");
-        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt) * sizeof(T);
+        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         struct { RolloutArgs<T> a; PersistArgs p; } both{a, p};
         size_t asz = sizeof(both);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
