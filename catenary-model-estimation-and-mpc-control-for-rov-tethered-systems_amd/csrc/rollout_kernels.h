@@ -1160,9 +1160,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & VELMASK) != 0;
             auto in_lds = [&](int sl) { return uses(sl) && !(VT == ROVMPC_VT_COMPOSE && ((VELMASK >> sl) & 1u)); };
             const int apslot = gen2 ? 16 : 13;
-            T xa[NEXO], xb[NEXO], xn[NEXO];
+            T xa[NEXO], xb[NEXO];
 #pragma unroll
-            for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl] = xn[sl] = T(0); if (in_lds(sl)) xa[sl] = RV_PX(sl, 0, c); }
+            for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl] = T(0); if (in_lds(sl)) xa[sl] = RV_PX(sl, 0, c); }
             // velocity-dependent slots of one node from (v, a, unit vector): simply.py:29-31, scaled
             auto vel_slots = [&](T *x, T vx, T vy, T vz, T ax, T ay, T az, T ux, T uy, T uz) {
                 if (uses(13)) {
@@ -1182,36 +1182,35 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (compose_rows)
                 vel_slots(xa, Vx, Vy, Vz, A0x, A0y, A0z, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c));
             // operands of a step: rotation axes and control of node n, unit vector of node n + 1
-            T o_ktx = T(0), o_kty = T(0), o_kgx = T(0), o_kgy = T(0), o_kgz = T(0), o_u0 = T(0), o_u1 = T(0), o_u2 = T(0), o_ux = T(0), o_uy = T(0), o_uz = T(0);
-            T p_ktx = T(0), p_kty = T(0), p_kgx = T(0), p_kgy = T(0), p_kgz = T(0), p_u0 = T(0), p_u1 = T(0), p_u2 = T(0), p_ux = T(0), p_uy = T(0), p_uz = T(0);
-            auto fetch_ops = [&](int n) {
+            struct Ops { T ktx, kty, kgx, kgy, kgz, u0, u1, u2, ux, uy, uz; };
+            Ops opA = {}, opB = {};
+            auto fetch_ops = [&](int n, Ops &o) {
                 if (!compose_rows) return;
-                p_ktx = RV_PL(sA, 0, n, c); p_kty = RV_PL(sA, 1, n, c);
-                p_kgx = RV_PL(sA, 2, n, c); p_kgy = RV_PL(sA, 3, n, c); p_kgz = RV_PL(sA, 4, n, c);
+                o.ktx = RV_PL(sA, 0, n, c); o.kty = RV_PL(sA, 1, n, c);
+                o.kgx = RV_PL(sA, 2, n, c); o.kgy = RV_PL(sA, 3, n, c); o.kgz = RV_PL(sA, 4, n, c);
                 const T *u = &sU[c * US + n * 3];
-                p_u0 = u[0]; p_u1 = u[1]; p_u2 = u[2];
-                if (uses(13)) { p_ux = RV_PL(sA, 5, n + 1, c); p_uy = RV_PL(sA, 6, n + 1, c); p_uz = RV_PL(sA, 7, n + 1, c); }
-            };
-            auto take_ops = [&]() {
-                o_ktx = p_ktx; o_kty = p_kty; o_kgx = p_kgx; o_kgy = p_kgy; o_kgz = p_kgz;
-                o_u0 = p_u0; o_u1 = p_u1; o_u2 = p_u2; o_ux = p_ux; o_uy = p_uy; o_uz = p_uz;
+                o.u0 = u[0]; o.u1 = u[1]; o.u2 = u[2];
+                if (uses(13)) { o.ux = RV_PL(sA, 5, n + 1, c); o.uy = RV_PL(sA, 6, n + 1, c); o.uz = RV_PL(sA, 7, n + 1, c); }
             };
             auto fetch_rows = [&](int node, T *x) {
 #pragma unroll
                 for (int sl = 0; sl < NEXO; ++sl) if (in_lds(sl)) x[sl] = RV_PX(sl, node, c);
             };
-            if (nsteps > 0) { fetch_ops(0); take_ops(); fetch_rows(1, xb); }
+            if (nsteps > 0) { fetch_ops(0, opA); fetch_rows(1, xb); }
             // sincos of the node state (velocity transform; anchor of the generation-2 slots)
             const bool need_trig = compose_rows || gen2;
             T st = T(0), ct = T(1), sg = T(0), cg = T(1);
             if (need_trig) { m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg); }
-            for (int n = 0; n < nsteps; ++n) {
-                if (n + 1 < nsteps) { fetch_ops(n + 1); fetch_rows(n + 2, xn); }
+            // One step: A = row of node n (start), B = row of node n + 1 (end; its velocity slots are built here), o = the
+            // step's operands, onext = where the next step's are fetched.  Once the third stage is through, A is dead and
+            // takes the row of node n + 2: the next step runs with the roles swapped, so the hand-over is a renaming.
+            auto one_step = [&](int n, T *A, T *B, const Ops &o, Ops &onext) {
+                if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
-                    const V3<T> kt = {o_ktx, o_kty, T(0)}, kg = {o_kgx, o_kgy, o_kgz};
-                    V3<T> v = rodrigues_unit<T>({o_u0, o_u1, o_u2}, kg, -sg, cg);
+                    const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
+                    V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
                     v = rodrigues_unit<T>(v, kt, st, ct);
-                    vel_slots(xb, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o_ux, o_uy, o_uz);
+                    vel_slots(B, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o.ux, o.uy, o.uz);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
@@ -1224,7 +1223,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     T x[18];
 #pragma unroll
                     for (int sl = 0; sl < NEXO; ++sl)
-                        x[sl] = cfrac2 == 0 ? xa[sl] : (cfrac2 == 2 ? xb[sl] : (xa[sl] + xb[sl]) / T(2));   // :62
+                        x[sl] = cfrac2 == 0 ? A[sl] : (cfrac2 == 2 ? B[sl] : (A[sl] + B[sl]) / T(2));   // :62
                     if (gen2) {
                         // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
                         x[16] = x[13];
@@ -1246,10 +1245,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (euler) {
                     thn = th + k1t * hstep;                                     // main_fun.py:761
                     gan = ga + k1g * hstep;
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);
                 } else {
                     T k2t, k2g, k3t, k3g, k4t, k4g;
                     stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
                     stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);                  // A is dead from here on
                     stage(th + hstep * k3t, ga + hstep * k3g, 2, k4t, k4g);
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
@@ -1262,10 +1263,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
                 // progress word for the early phase-4b batch (one wave's DS operations complete in order)
                 if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl]; if (in_lds(sl)) xb[sl] = xn[sl]; }
-                take_ops();
-            }
+            };
+            int n = 0;
+            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
+            if (n < nsteps) one_step(n, xa, xb, opA, opB);
         };
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
@@ -1279,9 +1280,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * kk.h, h6 = kk.h / T(6);
             const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & 0x3ffu) != 0;
             auto in_lds = [&](int p) { return uses(p) && VT != ROVMPC_VT_COMPOSE; };
-            T xa[10], xb[10], xn[10];
+            T xa[10], xb[10];
 #pragma unroll
-            for (int p = 0; p < 10; ++p) { xa[p] = xb[p] = xn[p] = T(0); if (in_lds(p)) xa[p] = RV_PX(p, 0, c); }
+            for (int p = 0; p < 10; ++p) { xa[p] = xb[p] = T(0); if (in_lds(p)) xa[p] = RV_PX(p, 0, c); }
             auto row = [&](T *x, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
                 const T r[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
 #pragma unroll
@@ -1290,38 +1291,34 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
             if (compose_rows)
                 dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
-            T o_ktx = T(0), o_kty = T(0), o_kgx = T(0), o_kgy = T(0), o_kgz = T(0), o_u0 = T(0), o_u1 = T(0), o_u2 = T(0), o_ux = T(0), o_uy = T(0), o_uz = T(0);
-            T p_ktx = T(0), p_kty = T(0), p_kgx = T(0), p_kgy = T(0), p_kgz = T(0), p_u0 = T(0), p_u1 = T(0), p_u2 = T(0), p_ux = T(0), p_uy = T(0), p_uz = T(0);
-            auto fetch_ops = [&](int n) {
+            struct Ops { T ktx, kty, kgx, kgy, kgz, u0, u1, u2, ux, uy, uz; };
+            Ops opA = {}, opB = {};
+            auto fetch_ops = [&](int n, Ops &o) {
                 if (!compose_rows) return;
-                p_ktx = RV_PL(sA, 0, n, c); p_kty = RV_PL(sA, 1, n, c);
-                p_kgx = RV_PL(sA, 2, n, c); p_kgy = RV_PL(sA, 3, n, c); p_kgz = RV_PL(sA, 4, n, c);
+                o.ktx = RV_PL(sA, 0, n, c); o.kty = RV_PL(sA, 1, n, c);
+                o.kgx = RV_PL(sA, 2, n, c); o.kgy = RV_PL(sA, 3, n, c); o.kgz = RV_PL(sA, 4, n, c);
                 const T *u = &sU[c * US + n * 3];
-                p_u0 = u[0]; p_u1 = u[1]; p_u2 = u[2];
-                p_ux = RV_PL(sA, 5, n + 1, c); p_uy = RV_PL(sA, 6, n + 1, c); p_uz = RV_PL(sA, 7, n + 1, c);
-            };
-            auto take_ops = [&]() {
-                o_ktx = p_ktx; o_kty = p_kty; o_kgx = p_kgx; o_kgy = p_kgy; o_kgz = p_kgz;
-                o_u0 = p_u0; o_u1 = p_u1; o_u2 = p_u2; o_ux = p_ux; o_uy = p_uy; o_uz = p_uz;
+                o.u0 = u[0]; o.u1 = u[1]; o.u2 = u[2];
+                o.ux = RV_PL(sA, 5, n + 1, c); o.uy = RV_PL(sA, 6, n + 1, c); o.uz = RV_PL(sA, 7, n + 1, c);
             };
             auto fetch_rows = [&](int node, T *x) {
 #pragma unroll
                 for (int p = 0; p < 10; ++p) if (in_lds(p)) x[p] = RV_PX(p, node, c);
             };
-            if (nsteps > 0) { fetch_ops(0); take_ops(); fetch_rows(1, xb); }
+            if (nsteps > 0) { fetch_ops(0, opA); fetch_rows(1, xb); }
             T st = T(0), ct = T(1), sg = T(0), cg = T(1);
             if (compose_rows) { m_sincos(y0, &st, &ct); m_sincos(y1, &sg, &cg); }
-            for (int n = 0; n < nsteps; ++n) {
-                if (n + 1 < nsteps) { fetch_ops(n + 1); fetch_rows(n + 2, xn); }
+            auto one_step = [&](int n, T *A, T *B, const Ops &o, Ops &onext) {
+                if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
-                    const V3<T> kt = {o_ktx, o_kty, T(0)}, kg = {o_kgx, o_kgy, o_kgz};
-                    V3<T> v = rodrigues_unit<T>({o_u0, o_u1, o_u2}, kg, -sg, cg);
+                    const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
+                    V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
                     v = rodrigues_unit<T>(v, kt, st, ct);
                     T sway_n, surge_n;
-                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, o_ux, o_uy, o_uz, sway_n, surge_n);
+                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, o.ux, o.uy, o.uz, sway_n, surge_n);
                     const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
-                    if (n == 0) row(xa, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);   // np.gradient's edge rule
-                    row(xb, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
+                    if (n == 0) row(A, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);   // np.gradient's edge rule
+                    row(B, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
                         (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
                     Vx = v.x; Vy = v.y; Vz = v.z; sway_p = sway_n; surge_p = surge_n;
                 }
@@ -1329,7 +1326,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     T x[18];
 #pragma unroll
                     for (int p = 0; p < 10; ++p)
-                        x[4 + p] = cfrac2 == 0 ? xa[p] : (cfrac2 == 2 ? xb[p] : (xa[p] + xb[p]) / T(2));
+                        x[4 + p] = cfrac2 == 0 ? A[p] : (cfrac2 == 2 ? B[p] : (A[p] + B[p]) / T(2));
                     x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                     x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
                     x[14] = x[15] = x[16] = x[17] = T(0);
@@ -1342,6 +1339,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (euler) {
                     n0 = y0 + y2 * hstep; n1 = y1 + y3 * hstep;                      // test_cluster.py:125-129
                     y2 = y2 + a1t * hstep; y3 = y3 + a1g * hstep;                    // :113-117
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);
                 } else {
                     const T r1t = y2, r1g = y3;
                     const T r2t = y2 + hh * a1t, r2g = y3 + hh * a1g;
@@ -1349,6 +1347,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     stage(y0 + hh * r1t, y1 + hh * r1g, r2t, r2g, 1, a2t, a2g);
                     const T r3t = y2 + hh * a2t, r3g = y3 + hh * a2g;
                     stage(y0 + hh * r2t, y1 + hh * r2g, r3t, r3g, 1, a3t, a3g);
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);                       // A is dead from here on
                     const T r4t = y2 + hstep * a3t, r4g = y3 + hstep * a3g;
                     stage(y0 + hstep * r3t, y1 + hstep * r3g, r4t, r4g, 2, a4t, a4g);
                     n0 = y0 + h6 * (r1t + T(2) * r2t + T(2) * r3t + r4t);
@@ -1363,10 +1362,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 y0 = n0; y1 = n1;
                 RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
                 if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int p = 0; p < 10; ++p) { xa[p] = xb[p]; if (in_lds(p)) xb[p] = xn[p]; }
-                take_ops();
-            }
+            };
+            int n = 0;
+            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
+            if (n < nsteps) one_step(n, xa, xb, opA, opB);
         };
         const bool wide = NT > nint;
         if (tid < nint) {
