@@ -127,7 +127,7 @@ def run_extras(out, args, cfg, model, dev):
         from rovmpc.closed_loop import run_closed_loop
         eng3 = rovmpc.Engine(cfg, model)
         runs = {}
-        for mode, kw in (("launch_per_step", {"persistent": False}), ("persistent", {"persistent": True})):
+        for mode, kw in (("launch_per_step", {"mode": "per_step"}), ("pipelined", {"mode": "pipelined"}), ("persistent", {"mode": "persistent"})):
             try:
                 run_closed_loop(eng3, 12, min(T, 200), feedback=True, **kw)            # warm-up
                 rep = run_closed_loop(eng3, 12, T, feedback=True, **kw)

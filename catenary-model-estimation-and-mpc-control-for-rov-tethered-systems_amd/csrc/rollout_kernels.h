@@ -85,8 +85,19 @@ template <typename T> struct RolloutArgs {
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
     int plant_feedback;           // 1: keep the model's own (theta, gamma) = first predicted node of this step's winner
-    unsigned long long *step_seq; // persistent closed loop (closed_loop_kernel): after the plant update the sweeper publishes
-    unsigned long long step_next; //   *step_seq = step_next, which the other workgroups poll before their next step; null otherwise
+    // Closed loop with the state handed over on the GPU (closed_loop_kernel / closed_loop_step_kernel; ring == null otherwise).
+    // Step g takes P0, P1, V1, A1 from its measured row exo_cur -- known before the loop starts -- and, with feedback and
+    // g > 0, (theta0, gamma0, theta_prev, gamma_prev) from ring[g & 3][4], which the sweeper of step g - 1 fills: gamma0 /
+    // gamma_prev EARLY (compiled-in model: gamma's path is candidate-invariant, so gamma_1 is known once that sweeper's own
+    // gamma chain is through; seq_gamma), theta0 / theta_prev once its arg-min is known (seq_theta).  Everything that does not
+    // hang on theta (controls -> LDS, node positions, the gamma table, phase 2b) therefore runs BEFORE the wait.
+    const double *exo_cur;
+    double *ring;
+    unsigned long long *seq_theta, *seq_gamma;
+    long long step;               // g
+    int from_ring;                // feedback && g > 0: (theta, gamma) come from the ring, else from exo_cur[12..15]
+    int wait_theta;               // wait for seq_theta >= g before the theta chain (from_ring, or back-pressure of the in-launch loop)
+    int publish;                  // g + 1 < T: the sweeper publishes for step g + 1
     int NT, nblocks;              // launch geometry (blockDim / gridDim are dependent loads through the implicit arguments)
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
     unsigned used_planes;         // bit s: exogenous plane s is read by the loaded expressions
@@ -208,7 +219,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         int j = 0;
         // 60 s of the 100 MHz clock; inside the persistent loop the hand-off timeout (a workgroup that gave up its own wait
         // never publishes, and the grid has to drain)
-        const unsigned long long give_up = wall_clock64() + (a.step_seq ? a.handoff_ticks : 6000000000ULL);
+        const unsigned long long give_up = wall_clock64() + (a.ring ? a.handoff_ticks : 6000000000ULL);
         for (unsigned it = 1;; ++it) {
             bool pending = false;
             for (;;) {
@@ -244,6 +255,13 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
+    if (a.ring && a.publish && tid < 64) {
+        // closed loop, GPU-side hand-off: the next step's (theta0, gamma0, theta_prev, gamma_prev) = nodes 1 and 0 of the
+        // winner, before anything else -- the record below is off the loop's critical path
+        if (a.plant_feedback && tid < 4) st_agent(&a.ring[(int)((a.step + 1) & 3) * 4 + tid], ld_agent(&bt[tid < 2 ? 2 + tid : tid - 2]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) st_agent(a.seq_theta, (unsigned long long)(a.step + 1));
+    }
     bool row_free = true;
     if (a.flag_consumed) {
         // the slot buffer is reused every few steps: its previous contents must have been read by that step's select.
@@ -298,23 +316,16 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     if (a.plant_next && tid < 16) {
         const double *plant_next = a.plant_next;
         double *plant_state = a.plant_state;
-        // persistent loop: the other workgroups read the state inside this launch -> write-through stores
-        auto put = [&](int i, double v) { if (a.step_seq) st_agent(&plant_state[i], v); else plant_state[i] = v; };
         if (!a.plant_feedback) {
-            put(tid, plant_next[tid]);
+            plant_state[tid] = plant_next[tid];
         } else if (tid < 12) {
-            put(tid, plant_next[tid]);
+            plant_state[tid] = plant_next[tid];
         } else if (tid == 12) {
-            const double th = a.step_seq ? ld_agent(&plant_state[12]) : plant_state[12];
-            const double ga = a.step_seq ? ld_agent(&plant_state[13]) : plant_state[13];
-            put(14, th); put(15, ga);
-            put(12, ld_agent(&bt[2])); put(13, ld_agent(&bt[3]));   // (theta, gamma) of node 1
+            // (theta, gamma) of this step = node 0 of the winner's trajectory, of the next = node 1
+            const double th = a.ring ? ld_agent(&bt[0]) : plant_state[12], ga = a.ring ? ld_agent(&bt[1]) : plant_state[13];
+            plant_state[14] = th; plant_state[15] = ga;
+            plant_state[12] = ld_agent(&bt[2]); plant_state[13] = ld_agent(&bt[3]);
         }
-    }
-    if (a.step_seq && tid < 64) {
-        // every store of the new state came from this wave: drain them, then the step number (the data's flag)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) st_agent(a.step_seq, a.step_next);
     }
 }
 
@@ -424,21 +435,26 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(0);
     // state: declared here (the gamma lambdas capture it), loaded after the controls' loads are in flight
     T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
-    // Persistent closed loop: the state was written by another workgroup inside this launch (the sweeper of the previous
-    // step), so it is fetched once with agent-scope loads into LDS and read from there; otherwise plain (scalar) loads.
-    __shared__ double s_state[ROVMPC_STATE_LEN];
-    if (PERSIST) {
-        if (tid < ROVMPC_STATE_LEN) s_state[tid] = ld_agent(&a.state[tid]);
-        __syncthreads();
-    }
-    const double *sdg = a.state + (size_t)prob * ROVMPC_STATE_LEN;
-    // state element i as a wave-uniform value (the LDS copy is made scalar again: one readfirstlane per half)
-    auto sd_at = [&](int i) -> double {
-        if (!PERSIST) return sdg[i];
-        const double v = s_state[i];
+    // (closed loop with GPU-side hand-off: the measured row of this step stands in for the state; theta / gamma arrive
+    // later, in the waves that need them -- ring_wait / ring_get)
+    const double *sdg = PERSIST ? a.exo_cur : a.state + (size_t)prob * ROVMPC_STATE_LEN;
+    auto sd_at = [&](int i) -> double { return sdg[i]; };
+    // Whole-wave call: lane 0 polls the sequence word until the record of this step is out (bounded: on giving up it raises
+    // the error word and the wave goes on with whatever the ring holds).
+    auto ring_wait = [&](const unsigned long long *seq) {
+        if ((tid & 63) == 0) {
+            const unsigned long long give_up = wall_clock64() + a.handoff_ticks;
+            while (ld_agent(seq) < (unsigned long long)a.step) {
+                if (wall_clock64() > give_up) { raise_error(a.err, ERR_SWEEP); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    };
+    auto ring_get = [&](int idx) -> T {                       // wave-uniform value
+        const double v = ld_agent(&a.ring[(a.step & 3) * 4 + idx]);
         const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(__double_as_longlong(v) & 0xffffffffLL));
         const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)__double_as_longlong(v) >> 32));
-        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        return (T)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     };
 
     // Compiled-in model: dgamma/dt = x15 - x17 reads gamma and its delay slot only -- no control, no
@@ -568,7 +584,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     };
     const int p2rem = (N + 1) % max(LNT >> cks, 1);    // nodes of the partial last round of phase 2a
     // (compiled-in model: the gamma wave integrates gamma and fills its table meanwhile)
-    if (gwave) { RV_STAMP_W(8); gamma_chain(); RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10); }
+    if (gwave) {
+        RV_STAMP_W(8);
+        if (PERSIST && a.from_ring) { ring_wait(a.seq_gamma); ga0 = ring_get(1); gam0 = ring_get(3); }
+        gamma_chain();
+        if (PERSIST) {
+            if (a.from_ring || a.plant_feedback) {
+                // sweeper: gamma_1 of this step is every candidate's gamma_1 -- the next step's gamma0, known already
+                if ((int)blockIdx.x == a.sweeper && a.publish && a.plant_feedback) {
+                    if ((tid & 63) == 0) {
+                        const int nb = (int)((a.step + 1) & 3) * 4;
+                        st_agent(&a.ring[nb + 1], (double)sG[5]);
+                        st_agent(&a.ring[nb + 3], (double)ga0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if ((tid & 63) == 0) st_agent(a.seq_gamma, (unsigned long long)(a.step + 1));
+                }
+            }
+            if ((tid & 63) == 0) sG[8 * N + 1] = ga0;           // phase 2b's gamma_0 (this wave alone knows it)
+        }
+        RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10);
+    }
     for (int i = (wideB && gwave) ? (N + 1) * CK : ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
         // node order: an item's cost grows with n (an n-term position sum), and the last round is partial.
         // Full rounds take the far nodes in ascending order (the first waves -- the theta wave among them --
@@ -685,7 +721,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         //   A = kty wz,  B = ktx (kt . w),  C = wx - B  (primes: scaled by 1/scale3, B' also shifted).
         for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
             const int n = i >> cks, c = i & ckm;
-            RV_PL(sY, 1, n, c) = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
+            RV_PL(sY, 1, n, c) = n == 0 ? (PERSIST ? sG[8 * N + 1] : ga0) : sG[8 * (n - 1) + 5];
             if (VT != ROVMPC_VT_COMPOSE || n == N) continue;
             const T ktx = RV_PL(sA, 0, n, c), kty = RV_PL(sA, 1, n, c);
             const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
@@ -798,6 +834,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T m3 = sMean[3], i3 = sInv[3], m16 = sMean[16], i16 = sInv[16];
             const T KT = T(0.048152514);
             const T hKT = euler ? kk.h * KT : (kk.h / T(6)) * KT;
+            if (PERSIST && a.wait_theta) {
+                ring_wait(a.seq_theta);
+                if (a.from_ring) { th0 = ring_get(0); thm0 = ring_get(2); }
+            }
             T th = th0, thm = thm0;
             if (live && role == 0) RV_PL(sY, 0, 0, c) = th;
             T x3a = (V0x - m3) * i3;
@@ -906,6 +946,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
         const int nint = 64;
         auto integrate = [&]() {
+            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+                ring_wait(a.seq_theta);
+                if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
+            }
             if (tid >= CK) return;
             const int c = tid;
             const int nsteps = (a.debug & 1) ? 0 : N;
@@ -1025,6 +1069,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // the half stages, simulate_rk4_theta_gamma.py:62).  integrator EULER = the reference's explicit double Euler
         // (test_cluster.py:113-129).  State slots 14/15 carry (dtheta, dgamma) at node 0.
         auto integrate_dd = [&]() {
+            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+                ring_wait(a.seq_theta);
+                if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
+            }
             if (tid >= CK) return;
             const int c = tid;
             const int nsteps = (a.debug & 1) ? 0 : N;
@@ -1146,6 +1194,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         };
         constexpr unsigned VELMASK = 0x21f8u;       // planes 3..8 and 13: velocity, acceleration, angle_proj
         auto integrate_jit = [&]() {
+            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+                ring_wait(a.seq_theta);
+                if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
+            }
             if (tid >= CK) return;
             const int c = tid;
             const int nsteps = (a.debug & 1) ? 0 : N;
@@ -1271,6 +1323,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
         auto integrate_dd_jit = [&]() {
+            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+                ring_wait(a.seq_theta);
+                if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
+            }
             if (tid >= CK) return;
             const int c = tid;
             const int nsteps = (a.debug & 1) ? 0 : N;
@@ -1518,35 +1574,39 @@ rollout_kernel(const RolloutArgs<T> a) {
 struct PersistArgs {
     long long T;                      // steps
     const double *exo;                // [T][16] measured rows (rovmpc_closed_loop_device)
-    unsigned long long *step_seq;     // states published so far (0 at launch: state 0 is already in a.state)
+    unsigned long long *seq_theta;    // steps whose (theta | gamma) record the sweepers have published (0 before the loop)
+    unsigned long long *seq_gamma;
+    double *ring;                     // [4][4], see RolloutArgs
+    unsigned long long *granules2;    // [2][3][nblocks] and
+    double *blk_traj2;                // [2][nblocks][N+1][2]: hand-off buffers by step parity (two steps can be in flight)
     long long pool_elems;             // K * N * 3
     int n_pools;
+    long long step_base;              // global index of this launch's first step (pipelined form: T = 1 per launch)
 };
 
-template <typename T, int MODEL, int VT>
+template <typename T, int MODEL, int VT, bool SINGLE = false>
 RV_DEV void closed_loop_body(const RolloutArgs<T> &a0, const PersistArgs &p) {
     const int R = 5 + 2 * (a0.N + 1);
-    int pool = 0;
-    for (long long i = 0; i < p.T; ++i) {
-        if (i > 0) {
-            bool gave_up = false;
-            if (threadIdx.x == 0) {
-                const unsigned long long give_up = wall_clock64() + a0.handoff_ticks;
-                while (ld_agent(p.step_seq) < (unsigned long long)i) {
-                    if (wall_clock64() > give_up) { gave_up = true; raise_error(a0.err, ERR_SWEEP); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            // (also the barrier that frees the LDS image of the previous step)
-            if (__syncthreads_or(gave_up)) return;
-        }
+    int pool = (int)(p.step_base % p.n_pools);
+    const long long steps = SINGLE ? 1 : p.T;
+    for (long long i = 0; i < steps; ++i) {
+        const long long g = p.step_base + i;          // global step
+        if (!SINGLE && i > 0) __syncthreads();        // the LDS image of the previous step is free
         RolloutArgs<T> a = a0;
         a.U = a0.U + (size_t)pool * p.pool_elems;
         a.result = a0.result + (size_t)i * R;
         a.epoch = a0.epoch + (unsigned)i;
-        a.plant_next = i + 1 < p.T ? p.exo + (size_t)(i + 1) * ROVMPC_STATE_LEN : nullptr;
+        a.granules = p.granules2 + (size_t)(g & 1) * 3 * a0.nblocks;
+        a.blk_traj = p.blk_traj2 + (size_t)(g & 1) * a0.nblocks * (a0.N + 1) * 2;
+        a.exo_cur = p.exo + (size_t)g * ROVMPC_STATE_LEN;
+        a.ring = p.ring; a.seq_theta = p.seq_theta; a.seq_gamma = p.seq_gamma;
+        a.step = g;
+        a.from_ring = a0.plant_feedback && g > 0;
+        // the in-launch loop also waits without feedback: a workgroup then runs at most one step ahead of the sweeper
+        a.wait_theta = a.from_ring || (!SINGLE && g > 0);
+        a.publish = g + 1 < p.T;
+        a.plant_next = g + 1 < p.T ? p.exo + (size_t)(g + 1) * ROVMPC_STATE_LEN : nullptr;
         a.plant_state = const_cast<double *>(a0.state);
-        a.step_seq = p.step_seq; a.step_next = (unsigned long long)(i + 1);
         rollout_body<T, MODEL, VT, true>(a);
         if (++pool == p.n_pools) pool = 0;
     }
@@ -1556,6 +1616,17 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 closed_loop_kernel(const RolloutArgs<T> a, const PersistArgs p) {
     closed_loop_body<T, MODEL, VT>(a, p);
+}
+
+// Pipelined form of the same hand-off: ONE step per launch (no loop around the body), launches alternating between two
+// streams.  Launch g + 1 starts while launch g is still running -- its launch latency, dispatch ramp and the previous
+// sweeper's epilogue leave the critical path -- and its workgroups wait on the step number for the state launch g's
+// sweeper publishes.  p.T is the length of the whole loop (the last step publishes no state), a.result / a.epoch are
+// already this step's.
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+closed_loop_step_kernel(const RolloutArgs<T> a, const PersistArgs p) {
+    closed_loop_body<T, MODEL, VT, true>(a, p);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

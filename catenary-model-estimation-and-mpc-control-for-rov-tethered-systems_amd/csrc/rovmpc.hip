@@ -33,7 +33,14 @@ struct rovmpc_handle {
     int model_kind = MODEL_INTERP;   // MODEL_BUILTIN | MODEL_INTERP | MODEL_JIT
     hipFunction_t jit_fn = nullptr;  // MODEL_JIT: kernel of the run-time specialised module
     hipFunction_t jit_fn_loop = nullptr;   //            its persistent closed-loop entry
-    unsigned long long *d_step_seq = nullptr;   // persistent closed loop: states published inside the running launch
+    hipFunction_t jit_fn_step = nullptr;   //            its pipelined closed-loop step entry
+    hipStream_t pipe_streams[2] = {nullptr, nullptr};     // pipelined closed loop: launches alternate between the two
+    hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};
+    // closed loop with GPU-side hand-off (persistent / pipelined): sequence words [2] + state ring [4][4] in one block,
+    // and the granule / trajectory hand-off buffers by step parity
+    unsigned long long *d_step_seq = nullptr;
+    unsigned long long *d_cl_granules = nullptr;
+    double *d_cl_blk_traj = nullptr;
     int n_feat = 0;
     double mean[ROVMPC_MAX_FEATURES], scale[ROVMPC_MAX_FEATURES];
     int n_th = 0, n_ga = 0, n_consts = 0;
@@ -364,7 +371,9 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
-                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1]};
+                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj};
+    for (auto &st : h->pipe_streams) if (st) (void)hipStreamDestroy(st);
+    for (auto &ev : h->pipe_ev) if (ev) (void)hipEventDestroy(ev);
     if (h->h_record) (void)hipHostFree(h->h_record);
     if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->h_err) (void)hipHostFree(h->h_err);
@@ -443,16 +452,16 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
     return st.empty() ? "m_nan<T>()" : st.back();
 }
 
-struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_loop = nullptr; };
+struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_loop = nullptr, fn_step = nullptr; };
 static std::mutex g_jit_mu;
 static std::map<std::string, JitModule> g_jit_cache;     // key: device ordinal + generated source
 
 // Returns nullptr and fills `why` when hiprtc cannot produce the kernel.
-static hipFunction_t jit_build(int device, const std::string &src, std::string &why, hipFunction_t *fn_loop) {
+static hipFunction_t jit_build(int device, const std::string &src, std::string &why, hipFunction_t *fn_loop, hipFunction_t *fn_step) {
     std::lock_guard<std::mutex> lk(g_jit_mu);
     const std::string key = std::to_string(device) + "\n" + src;
     auto it = g_jit_cache.find(key);
-    if (it != g_jit_cache.end()) { *fn_loop = it->second.fn_loop; return it->second.fn; }
+    if (it != g_jit_cache.end()) { *fn_loop = it->second.fn_loop; *fn_step = it->second.fn_step; return it->second.fn; }
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {k_src_rovmpc_h, k_src_device_math_h, k_src_rollout_kernels_h};
     const char *hdr_name[] = {"rovmpc.h", "device_math.h", "rollout_kernels.h"};
@@ -484,8 +493,9 @@ static hipFunction_t jit_build(int device, const std::string &src, std::string &
     e = hipModuleGetFunction(&m.fn, m.mod, "rovmpc_rollout_jit");
     if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); (void)hipModuleUnload(m.mod); return nullptr; }
     if (hipModuleGetFunction(&m.fn_loop, m.mod, "rovmpc_closed_loop_jit") != hipSuccess) m.fn_loop = nullptr;
+    if (hipModuleGetFunction(&m.fn_step, m.mod, "rovmpc_closed_loop_step_jit") != hipSuccess) m.fn_step = nullptr;
     g_jit_cache[key] = m;
-    *fn_loop = m.fn_loop;
+    *fn_loop = m.fn_loop; *fn_step = m.fn_step;
     return m.fn;
 }
 
@@ -506,6 +516,8 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
          "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a, p);\n}\n";
+    s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
+         "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", true>(a, p);\n}\n";
     return s;
 }
 
@@ -650,12 +662,12 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     }
     h->builtin = same;
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
-    h->jit_fn = nullptr; h->jit_fn_loop = nullptr;
+    h->jit_fn = nullptr; h->jit_fn_loop = nullptr; h->jit_fn_step = nullptr;
     h->err.clear();
     if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features <= 18) {
         std::string why;
         const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
-        hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_loop);
+        hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_loop, &h->jit_fn_step);
         if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; }
         else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
     }
@@ -704,7 +716,8 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.epoch = *h->epoch_ctr;
     a.NT = g.NT; a.nblocks = g.nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
-    a.step_seq = nullptr; a.step_next = 0;
+    a.ring = nullptr; a.exo_cur = nullptr; a.seq_theta = nullptr; a.seq_gamma = nullptr;
+    a.step = 0; a.from_ring = 0; a.wait_theta = 0; a.publish = 0;
     a.result_host = h->arg_result_host; a.done_flag = h->arg_done_flag; a.done_seq = h->arg_done_seq;
     a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
     a.consumed_need = h->arg_consumed_need; a.rolled_seq = h->arg_rolled_seq;
@@ -1696,6 +1709,23 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
 
 // ---- closed loop ----------------------------------------------------------------------------------
 
+// Workspace of the GPU-side closed-loop hand-off; fills the pointers of `p` and zeroes the sequence words on `s`.
+static int closed_loop_workspace(rovmpc_handle *h, PersistArgs &p, hipStream_t s) {
+    const rovmpc_config &c = h->cfg;
+    const size_t max_blocks = c.candidates_per_block > 0 ? (size_t)((c.K + c.candidates_per_block - 1) / c.candidates_per_block) : (size_t)c.K;
+    if (!h->d_step_seq) {
+        HIPCHK(h, hipMalloc((void **)&h->d_step_seq, 256));
+        HIPCHK(h, hipMalloc((void **)&h->d_cl_granules, 2 * 3 * max_blocks * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->d_cl_granules, 0, 2 * 3 * max_blocks * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc((void **)&h->d_cl_blk_traj, 2 * max_blocks * (size_t)(c.N + 1) * 2 * sizeof(double)));
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_step_seq, 0, 256, s));
+    p.seq_theta = h->d_step_seq; p.seq_gamma = h->d_step_seq + 8;             // separate 64-byte lines
+    p.ring = reinterpret_cast<double *>(h->d_step_seq + 16);                   // [4][4] doubles
+    p.granules2 = h->d_cl_granules; p.blk_traj2 = h->d_cl_blk_traj;
+    return ROVMPC_OK;
+}
+
 template <typename T, int VT>
 static hipError_t launch_loop(const rovmpc_handle *h, const RolloutArgs<T> &a, const PersistArgs &p, hipStream_t s, int *capacity) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
@@ -1722,11 +1752,12 @@ static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64
     if (g.nblocks > h->n_cu)
         FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop needs the whole grid resident: %d workgroups > %d compute units "
                                         "(use rovmpc_closed_loop_device)", g.nblocks, h->n_cu);
-    if (!h->d_step_seq) HIPCHK(h, hipMalloc((void **)&h->d_step_seq, 64));
-    HIPCHK(h, hipMemsetAsync(h->d_step_seq, 0, 64, s));
+    PersistArgs p;
+    int rcw = closed_loop_workspace(h, p, s);
+    if (rcw) return rcw;
     // T consecutive epochs tag the granules of the T steps; the tag is never 0 and never repeats within the buffer's life
     if ((unsigned long long)*h->epoch_ctr + (unsigned long long)T_steps + 1 >= 0xffffffffULL) {
-        HIPCHK(h, hipMemsetAsync(h->d_granules, 0, (size_t)3 * g.nblocks * sizeof(unsigned long long), s));
+        HIPCHK(h, hipMemsetAsync(h->d_cl_granules, 0, (size_t)2 * 3 * g.nblocks * sizeof(unsigned long long), s));
         *h->epoch_ctr = 0;
     }
     hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
@@ -1738,8 +1769,7 @@ static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64
     *h->epoch_ctr += (unsigned)(T_steps - 1);
     a.result = d_results; a.k_offset = 0; a.slots = nullptr; a.rank = 0; a.world = 1;
     a.sweeper = 0;
-    PersistArgs p;
-    p.T = T_steps; p.exo = d_exo; p.step_seq = h->d_step_seq; p.n_pools = n_pools;
+    p.T = T_steps; p.exo = d_exo; p.n_pools = n_pools; p.step_base = 0;
     p.pool_elems = (long long)h->cfg.K * h->cfg.N * 3;
     const int vt = h->cfg.vt_mode;
     hipError_t e = hipSuccess;
@@ -1760,6 +1790,122 @@ static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64
     if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "persistent closed-loop launch failed: %s", hipGetErrorString(e));
     if (a.nblocks > capacity) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop: %d workgroups exceed the device's resident capacity %d", a.nblocks, capacity);
     return ROVMPC_OK;
+}
+
+// ---- pipelined closed loop: one step per launch, launches alternating between two streams -----------------------
+template <typename T, int VT>
+static hipError_t launch_step(const rovmpc_handle *h, const RolloutArgs<T> &a, const PersistArgs &p, hipStream_t s, bool probe, int *capacity) {
+    const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
+    auto kern = closed_loop_step_kernel<T, MODEL_BUILTIN, VT>;
+    if (probe) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        int per_cu = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, a.NT, lds);
+        if (e != hipSuccess) return e;
+        *capacity = per_cu * h->n_cu;
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(a.NT), lds, s, a, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_t T_steps, double *d_state, const void *d_pools,
+                                   int32_t n_pools, int32_t feedback, double *d_results, hipStream_t s) {
+    Geo g = launch_geometry(h, 1);
+    // Two launches are in flight at any time (launch g + 1 may start once launch g - 1 is complete), and the later one's
+    // workgroups hold their CU slots while they wait for the earlier one's sweeper: both grids must fit the chip at once,
+    // whatever order the two queues dispatch in.  Four-wave workgroups share a CU three at a time (measured with the HW_ID
+    // stamp), five-wave ones do not: unless the caller fixed the geometry, use 256 threads.
+    if (h->cfg.threads_per_block == 0 && h->cfg.candidates_per_block == 0 && g.NT > 256 && g.CK <= 16) g.NT = 256;
+    if (!h->pipe_streams[0]) {
+        // two streams of different priority: same-priority streams can share a hardware queue, and then nothing overlaps
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->pipe_streams[0], hipStreamNonBlocking, lo));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->pipe_streams[1], hipStreamNonBlocking, hi));
+        for (auto &ev : h->pipe_ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int vt = h->cfg.vt_mode;
+    const size_t R = rovmpc_result_len(h);
+    RolloutArgs<T> a;
+    PersistArgs p;
+    int rcw = closed_loop_workspace(h, p, s);
+    if (rcw) return rcw;
+    p.T = T_steps; p.exo = d_exo; p.n_pools = n_pools;
+    p.pool_elems = (long long)h->cfg.K * h->cfg.N * 3;
+    int capacity = 0;
+    if (h->model_kind == MODEL_BUILTIN) {
+        h->plant_feedback = 0;
+        fill_args<T>(h, a, d_state, d_pools, nullptr, g, 1);
+        --*h->epoch_ctr;                                         // (the probe takes no epoch)
+        hipError_t e = vt == 0 ? launch_step<T, 0>(h, a, p, s, true, &capacity) : vt == 1 ? launch_step<T, 1>(h, a, p, s, true, &capacity)
+                                                                                      : launch_step<T, 2>(h, a, p, s, true, &capacity);
+        if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+    } else if (h->model_kind == MODEL_JIT) {
+        if (!h->jit_fn_step) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the run-time specialised module has no pipelined entry");
+        capacity = 2 * g.nblocks <= 2 * h->n_cu ? 2 * h->n_cu : 0;   // one 16-candidate workgroup per CU and launch: two fit a CU's LDS / wave slots
+        const size_t lds = rollout_lds_elems<T>(h->cfg.N, g.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+        if (lds > 80 * 1024) capacity = 0;
+    } else {
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "pipelined closed loop: compiled-in and hiprtc-specialised models only (the interpreter runs launch per step)");
+    }
+    if (2 * g.nblocks > capacity)
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "pipelined closed loop needs two grids resident at once: 2 x %d workgroups exceed the device's capacity %d "
+                                        "(use rovmpc_closed_loop_device)", g.nblocks, capacity);
+    hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->pipe_ev[2], s));
+    for (auto &st : h->pipe_streams) HIPCHK(h, hipStreamWaitEvent(st, h->pipe_ev[2], 0));
+    for (int64_t i = 0; i < T_steps; ++i) {
+        hipStream_t st = h->pipe_streams[i & 1];
+        h->plant_feedback = feedback ? 1 : 0;
+        fill_args<T>(h, a, d_state, (const char *)d_pools + (size_t)(i % n_pools) * p.pool_elems * sizeof(T), nullptr, g, 1);   // one epoch per step
+        h->plant_feedback = 0;
+        a.result = d_results + (size_t)i * R; a.k_offset = 0; a.slots = nullptr; a.rank = 0; a.world = 1;
+        a.sweeper = 0;
+        p.step_base = i;
+        PersistArgs pi = p;
+        pi.n_pools = 1;                                          // a.U is already this step's pool
+        hipError_t e;
+        if (h->model_kind == MODEL_JIT) {
+            const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            struct { RolloutArgs<T> a; PersistArgs p; } both{a, pi};
+            size_t asz = sizeof(both);
+            void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            e = hipModuleLaunchKernel(h->jit_fn_step, a.nblocks, 1, 1, a.NT, 1, 1, (unsigned)lds, st, nullptr, extra);
+        } else {
+            e = vt == 0 ? launch_step<T, 0>(h, a, pi, st, false, &capacity) : vt == 1 ? launch_step<T, 1>(h, a, pi, st, false, &capacity)
+                                                                                      : launch_step<T, 2>(h, a, pi, st, false, &capacity);
+        }
+        if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "pipelined closed-loop launch failed: %s", hipGetErrorString(e));
+    }
+    for (int j = 0; j < 2; ++j) {
+        HIPCHK(h, hipEventRecord(h->pipe_ev[j], h->pipe_streams[j]));
+        HIPCHK(h, hipStreamWaitEvent(s, h->pipe_ev[j], 0));
+    }
+    return ROVMPC_OK;
+}
+
+extern "C" int rovmpc_closed_loop_pipelined_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
+                                                   const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
+                                                   void *stream) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (T < 1 || n_pools < 1 || !d_exo || !d_state || !d_pools || !d_results)
+        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_closed_loop_pipelined_device: bad argument");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (h->comm) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "pipelined closed loop is single-GPU: the sharded loop needs a host-issued collective per step");
+    if (feedback && h->cfg.feature_map == ROVMPC_FEATURES_GEN3)
+        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "closed loop with model feedback carries (theta, gamma) only (see rovmpc_closed_loop_device)");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return h->cfg.dtype == ROVMPC_F64
+               ? closed_loop_pipelined_t<double>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream)
+               : closed_loop_pipelined_t<float>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream);
 }
 
 extern "C" int rovmpc_closed_loop_persistent_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,

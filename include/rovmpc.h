@@ -277,6 +277,15 @@ int rovmpc_closed_loop_persistent_device(rovmpc_handle *h, const double *d_exo, 
                                          const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
                                          void *stream);
 
+/* The same loop, pipelined: one step per launch, launches alternating between two internal streams (forked from and joined
+ * to `stream`).  Launch i + 1 starts while launch i runs -- its launch latency, dispatch ramp and the previous sweeper's
+ * epilogue leave the critical path -- and its workgroups wait, on the GPU, for the state launch i's sweeper publishes.
+ * Records are bit-identical to rovmpc_closed_loop_device's.  ROVMPC_ERR_UNSUPPORTED when two grids do not fit the chip
+ * at once, with a communicator, or for the bytecode interpreter. */
+int rovmpc_closed_loop_pipelined_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
+                                        const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
+                                        void *stream);
+
 /* Per-launch timing of the rollout kernel with HIP events on the launch stream. */
 int rovmpc_timing_enable(rovmpc_handle *h, int32_t max_launches);
 int rovmpc_timing_read(rovmpc_handle *h, double *avg_ms, double *min_ms, int32_t *count);

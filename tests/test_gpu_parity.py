@@ -882,17 +882,21 @@ def test_config5_size_closed_loop_10000_steps(rv):
         assert rep.u.shape == (10000, 3) and rep.theta_gamma.shape == (10001, 2)
 
 
+@pytest.mark.parametrize("mode", ["persistent", "pipelined"])
 @pytest.mark.parametrize("feedback", [False, True])
 @pytest.mark.parametrize("K,N,steps,kw", [(4096, 20, 300, {}), (1024, 20, 64, {"dtype": "f32"}), (512, 12, 40, {"no_builtin": True}),
                                            (4096, 20, 40, {"vt_mode": 0})])
-def test_persistent_closed_loop_equals_launch_per_step(rv, K, N, steps, kw, feedback):
-    """rovmpc_closed_loop_persistent_device (one launch, T steps, in-kernel step hand-off) must reproduce the records of
-    the launch-per-step loop bit for bit, with measured rows and with the model's own (theta, gamma) fed back."""
+def test_persistent_closed_loop_equals_launch_per_step(rv, K, N, steps, kw, feedback, mode):
+    """rovmpc_closed_loop_persistent_device (one launch, T steps, in-kernel step hand-off) and
+    rovmpc_closed_loop_pipelined_device (one launch per step on two alternating streams, the same hand-off between launches)
+    must reproduce the records of the launch-per-step loop bit for bit, with measured rows and with the model's own
+    (theta, gamma) fed back."""
     from rovmpc.closed_loop import run_closed_loop
     with rv.Engine(rv.MPCConfig(N=N, K=K, **kw)) as e:
-        a = run_closed_loop(e, 12, steps, feedback=feedback, persistent=False)
-        b = run_closed_loop(e, 12, steps, feedback=feedback, persistent=True)
-        c = run_closed_loop(e, 12, steps, feedback=feedback, persistent=True)        # epochs advance, buffers are reusable
+        e.set_option("handoff_timeout_ms", 2000.0)
+        a = run_closed_loop(e, 12, steps, feedback=feedback, mode="per_step")
+        b = run_closed_loop(e, 12, steps, feedback=feedback, mode=mode)
+        c = run_closed_loop(e, 12, steps, feedback=feedback, mode=mode)              # epochs advance, buffers are reusable
         e.device_status()                                                             # no hand-off gave up
     for r in (b, c):
         if kw.get("dtype") == "f32":
