@@ -279,6 +279,29 @@ static Geo launch_geometry(const rovmpc_handle *h, int B) {
     return g;
 }
 
+// One high-priority stream per device for the whole process, created (and used once, so that the runtime binds it to a
+// hardware queue) by the first rovmpc_create on that device: the second stream of the pipelined closed loop.  Measured: the
+// same stream created later -- after other streams of the process have run kernels side by side -- can land on a queue
+// that serialises with the caller's (31 us per step instead of 15); created first, it keeps its queue whatever comes after.
+static std::mutex g_pipe_mu;
+static std::map<int, hipStream_t> g_pipe_stream;
+static hipStream_t process_pipe_stream(int device) {
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    auto it = g_pipe_stream.find(device);
+    if (it != g_pipe_stream.end()) return it->second;
+    hipStream_t st = nullptr;
+    int lo = 0, hi = 0;
+    void *scratch = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) st = nullptr;
+    if (st && hipMalloc(&scratch, 256) == hipSuccess) {
+        (void)hipMemsetAsync(scratch, 0, 256, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(scratch);
+    }
+    g_pipe_stream[device] = st;
+    return st;
+}
+
 extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     rovmpc_handle *nullh = nullptr;
     if (!cfg || !out) FAIL(nullh, ROVMPC_ERR_INVALID, "rovmpc_create: null argument");
@@ -333,6 +356,7 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     } while (0)
     CR(hipSetDevice(cfg->device));
     CR(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->pipe_streams[1] = process_pipe_stream(cfg->device);
     const size_t R = 5 + 2 * (size_t)(cfg->N + 1);
     CR(hipMalloc(&h->d_U, (size_t)cfg->K * cfg->N * 3 * h->esz));
     CR(hipMalloc(&h->d_J, (size_t)cfg->K * h->esz));
@@ -372,7 +396,6 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
                     h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj};
-    for (auto &st : h->pipe_streams) if (st) (void)hipStreamDestroy(st);
     for (auto &ev : h->pipe_ev) if (ev) (void)hipEventDestroy(ev);
     if (h->h_record) (void)hipHostFree(h->h_record);
     if (h->h_done) (void)hipHostFree(h->h_done);
@@ -1821,14 +1844,11 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     // whatever order the two queues dispatch in.  Four-wave workgroups share a CU three at a time (measured with the HW_ID
     // stamp), five-wave ones do not: unless the caller fixed the geometry, use 256 threads.
     if (h->cfg.threads_per_block == 0 && h->cfg.candidates_per_block == 0 && g.NT > 256 && g.CK <= 16) g.NT = 256;
-    if (!h->pipe_streams[0]) {
-        // two streams of different priority: same-priority streams can share a hardware queue, and then nothing overlaps
-        int lo = 0, hi = 0;
-        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(h, hipStreamCreateWithPriority(&h->pipe_streams[0], hipStreamNonBlocking, lo));
-        HIPCHK(h, hipStreamCreateWithPriority(&h->pipe_streams[1], hipStreamNonBlocking, hi));
+    // The launches alternate between the caller's stream and the process's high-priority stream (process_pipe_stream):
+    // streams of equal priority can share a hardware queue, and then nothing overlaps.
+    if (!h->pipe_streams[1]) FAIL(h, ROVMPC_ERR_HIP, "no second stream for the pipelined closed loop");
+    if (!h->pipe_ev[0])
         for (auto &ev : h->pipe_ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
     const int vt = h->cfg.vt_mode;
     const size_t R = rovmpc_result_len(h);
     RolloutArgs<T> a;
@@ -1859,9 +1879,9 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->pipe_ev[2], s));
-    for (auto &st : h->pipe_streams) HIPCHK(h, hipStreamWaitEvent(st, h->pipe_ev[2], 0));
+    HIPCHK(h, hipStreamWaitEvent(h->pipe_streams[1], h->pipe_ev[2], 0));
     for (int64_t i = 0; i < T_steps; ++i) {
-        hipStream_t st = h->pipe_streams[i & 1];
+        hipStream_t st = (i & 1) ? h->pipe_streams[1] : s;
         h->plant_feedback = feedback ? 1 : 0;
         fill_args<T>(h, a, d_state, (const char *)d_pools + (size_t)(i % n_pools) * p.pool_elems * sizeof(T), nullptr, g, 1);   // one epoch per step
         h->plant_feedback = 0;
@@ -1884,10 +1904,8 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
         }
         if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "pipelined closed-loop launch failed: %s", hipGetErrorString(e));
     }
-    for (int j = 0; j < 2; ++j) {
-        HIPCHK(h, hipEventRecord(h->pipe_ev[j], h->pipe_streams[j]));
-        HIPCHK(h, hipStreamWaitEvent(s, h->pipe_ev[j], 0));
-    }
+    HIPCHK(h, hipEventRecord(h->pipe_ev[1], h->pipe_streams[1]));
+    HIPCHK(h, hipStreamWaitEvent(s, h->pipe_ev[1], 0));
     return ROVMPC_OK;
 }
 

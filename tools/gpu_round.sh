@@ -14,6 +14,6 @@ python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/bench_default.json").read().strip().splitlines()[-1])
 print("headline us", d["ms_per_step"] * 1e3, "batched", [(r["B"], round(r["value"] / 1e9, 2)) for r in d["batched"]["runs"]])
-print("closed_loop", json.dumps(d.get("closed_loop", {}).get("modes")))
+print("closed_loop", json.dumps(d.get("closed_loop", {}).get("modes")), "2-in-flight us", d.get("two_steps_in_flight", {}).get("ms_per_step"))
 PY
 for cmd in "$@"; do echo "== $cmd"; timeout -k 10 600 bash -c "$cmd" 2>&1 | tail -12; done
