@@ -194,7 +194,7 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 // order-preserving int64 image of the record into slots[rank][*] and INT64_MAX elsewhere
 // (input of the single all-reduce(min) of the candidate-sharded step).  `scratch` = 16
 // doubles of LDS.
-template <typename T>
+template <typename T, bool LEAN = false>
 RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *granules, const double *blk_traj, const T *U,
                             double *result, double *scratch) {
     const int nblocks = a.nblocks, N = a.N, CK = a.CK, NT = a.NT, rank = a.rank, world = a.world;
@@ -255,7 +255,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
-    if (a.ring && a.publish && tid < 64) {
+    if (!LEAN && a.ring && a.publish && tid < 64) {
         // closed loop, GPU-side hand-off: the next step's (theta0, gamma0, theta_prev, gamma_prev) = nodes 1 and 0 of the
         // winner, before anything else -- the record below is off the loop's critical path
         if (a.plant_feedback && tid < 4) st_agent(&a.ring[(int)((a.step + 1) & 3) * 4 + tid], ld_agent(&bt[tid < 2 ? 2 + tid : tid - 2]));
@@ -263,7 +263,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         if (tid == 0) st_agent(a.seq_theta, (unsigned long long)(a.step + 1));
     }
     bool row_free = true;
-    if (a.flag_consumed) {
+    if (!LEAN && a.flag_consumed) {
         // the slot buffer is reused every few steps: its previous contents must have been read by that step's select.
         // If that never happens (a failed collective) the row is NOT rewritten: the error word and the slot's
         // bad-use mark make this step's global record a NaN and rovmpc_comm_sync an error.
@@ -288,14 +288,14 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
         else v = ld_agent(&bt[i - 5]);
         result[i] = v;
-        if (a.result_host) a.result_host[i] = v;
-        if (slots && row_free) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
+        if (!LEAN && a.result_host) a.result_host[i] = v;
+        if (!LEAN && slots && row_free) st_agent(&slots[(size_t)rank * R + i], ordered_key(v));
     }
-    if (slots && row_free) {
+    if (!LEAN && slots && row_free) {
         for (int i = tid; i < world * R; i += NT)
             if (i / R != rank) st_agent(&slots[i], 0x7fffffffffffffffLL);
     }
-    if (a.done_flag) {
+    if (!LEAN && a.done_flag) {
         // the record went to host memory: drain every wave's stores, then release the sequence number the host spins on
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -304,7 +304,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
             __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (a.flag_rolled && !(a.inject & 1)) {
+    if (!LEAN && a.flag_rolled && !(a.inject & 1)) {
         // publish: the row went out write-through at agent scope; once every wave's stores are acknowledged the
         // sequence number follows (the collective stream's wait kernel polls it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -313,7 +313,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     }
     // Closed loop on one GPU: the plant update of the next step (plant_update_kernel's rule) rides on this
     // workgroup -- every other workgroup has finished, nobody reads the state any more.
-    if (a.plant_next && tid < 16) {
+    if (!LEAN && a.plant_next && tid < 16) {
         const double *plant_next = a.plant_next;
         double *plant_state = a.plant_state;
         if (!a.plant_feedback) {
@@ -387,7 +387,10 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     return e;
 }
 
-template <typename T, int MODEL, int VT, bool PERSIST = false>
+// LEAN: the plain single-problem step (rovmpc_step_device and the host-pointer entry points): one problem, no slot image,
+// no hand-off flags, no host mirror, no plant update -- those branches are compiled out (measured on one box: the full
+// kernel is 0.3 us slower per C2 step than the round-1 kernel, which had none of them).
+template <typename T, int MODEL, int VT, bool PERSIST = false, bool LEAN = false>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -409,7 +412,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const int k0 = blockIdx.x * CK;
     // Batched launch (rovmpc_step_batch_device): blockIdx.y = problem.  Every per-problem array is the single-problem
     // array repeated B times; a problem's workgroups, granules, sweeper and record never touch another problem's.
-    const int prob = blockIdx.y;
+    const int prob = LEAN ? 0 : (int)blockIdx.y;
     const T *Ub = a.U + (size_t)prob * K * N * 3;
     const int nvalid = min(CK, K - k0);
     const unsigned used_lds = MODEL == MODEL_JIT ? jit_lds_planes(used, VT, fmap) : used;
@@ -1541,6 +1544,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     if ((int)blockIdx.x != a.sweeper) return;
     if (PERSIST) {
         argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
+    } else if (LEAN) {
+        argmin_epilogue<T, true>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
     } else {
         // The epilogue's own arguments (hand-off flags, slot buffer, plant update, host mirror ...) are cold: one workgroup
         // reads them once.  Read here through the kernarg segment pointer made opaque, their scalar loads cannot be
@@ -1561,6 +1566,12 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_lean(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true>(a);
 }
 
 // ---- persistent closed loop --------------------------------------------------------------------------------------

@@ -752,7 +752,10 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
 template <typename T, int MODEL, int VT>
 static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, int B, hipStream_t s) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL, VT) * sizeof(T);
-    auto kern = rollout_kernel<T, MODEL, VT>;
+    // the plain single-problem step of the compiled-in model takes the lean instantiation (see rollout_body)
+    const bool lean = MODEL == MODEL_BUILTIN && B == 1 && !a.slots && !a.flag_consumed && !a.flag_rolled && !a.result_host &&
+                      !a.done_flag && !a.plant_next;
+    auto kern = lean ? rollout_kernel_lean<T, MODEL, VT> : rollout_kernel<T, MODEL, VT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
