@@ -180,6 +180,13 @@ RV_DEV void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic
 RV_DEV unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // The workgroup's best as three tagged granules (epoch << 32 | 32 payload bits): cost high word, cost low word,
 // winning lane.  The reader takes a workgroup's record only when all three tags equal this launch's epoch.
+// A fourth granule per workgroup says that its best trajectory (write-through stores) has been acknowledged: the cost
+// granules go out WITHOUT waiting for that drain, so the sweep sees a workgroup's cost ~0.7 us earlier, and only the
+// winner's trajectory flag is waited for (it is almost always up by then).
+constexpr int GRAN = 4;
+RV_DEV void publish_traj_ready(unsigned long long *granules, int nblocks, unsigned epoch) {
+    st_agent(granules + 3 * (size_t)nblocks + blockIdx.x, (unsigned long long)epoch << 32);
+}
 RV_DEV void publish_best(unsigned long long *granules, int nblocks, unsigned epoch, double cost, unsigned lane) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(cost), tag = (unsigned long long)epoch << 32;
     st_agent(granules + blockIdx.x, tag | (bits >> 32));
@@ -255,6 +262,18 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     const double Jbest = sJ[0];
     const int R = 5 + 2 * (N + 1);
     const double *bt = blk_traj + (size_t)(kbest / CK) * (N + 1) * 2;
+    if (Jbest == Jbest) {
+        // the winner's trajectory must be out (its flag granule; the cost granules did not wait for it)
+        if (tid == 0) {
+            const unsigned long long *f = granules + 3 * (size_t)nblocks + (size_t)(kbest / CK);
+            const unsigned long long give_up = wall_clock64() + (a.ring ? a.handoff_ticks : 6000000000ULL);
+            while ((unsigned)(ld_agent(f) >> 32) != epoch) {
+                if (wall_clock64() > give_up) { raise_error(a.err, ERR_SWEEP); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
     if (!LEAN && a.ring && a.publish && tid < 64) {
         // closed loop, GPU-side hand-off: the next step's (theta0, gamma0, theta_prev, gamma_prev) = nodes 1 and 0 of the
         // winner, before anything else -- the record below is off the loop's critical path
@@ -1454,7 +1473,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *Jb = a.J + (size_t)prob * K;
     T *trajb = a.traj_all ? a.traj_all + (size_t)prob * K * (N + 1) * 2 : nullptr;
     double *blk_trajb = a.blk_traj + (size_t)prob * a.nblocks * (N + 1) * 2;
-    unsigned long long *granb = a.granules + (size_t)prob * 3 * a.nblocks;
+    unsigned long long *granb = a.granules + (size_t)prob * GRAN * a.nblocks;
     double *resultb = a.result ? a.result + (size_t)prob * (5 + 2 * (N + 1)) : nullptr;
     const bool fast_tail = resultb && !a.traj_all && N + 1 <= 64;
     double &s_best_J = *reinterpret_cast<double *>(reinterpret_cast<char *>(smem) + 16);   // header bytes 16..23
@@ -1503,8 +1522,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 st_agent(&bt[2 * c], (double)RV_PL(sY, 0, c, cb));
                 st_agent(&bt[2 * c + 1], (double)RV_PL(sY, 1, c, cb));
             }
+            if (c == 0) publish_best(granb, a.nblocks, a.epoch, Jd, (unsigned)cb);     // the cost does not wait for the drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (c == 0) publish_best(granb, a.nblocks, a.epoch, Jd, (unsigned)cb);
+            if (c == 0) publish_traj_ready(granb, a.nblocks, a.epoch);
         } else if (c == 0) {
             s_best_J = Jd;
         }
@@ -1538,7 +1558,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // until all carry the epoch.  No assumption on dispatch order, timing or XCD placement.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) publish_best(granb, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c);
+    if (tid == 0) { publish_best(granb, a.nblocks, a.epoch, s_best_J, (unsigned)*s_best_c); publish_traj_ready(granb, a.nblocks, a.epoch); }
     }
     RV_STAMP(7);
     if ((int)blockIdx.x != a.sweeper) return;
@@ -1607,7 +1627,7 @@ RV_DEV void closed_loop_body(const RolloutArgs<T> &a0, const PersistArgs &p) {
         a.U = a0.U + (size_t)pool * p.pool_elems;
         a.result = a0.result + (size_t)i * R;
         a.epoch = a0.epoch + (unsigned)i;
-        a.granules = p.granules2 + (size_t)(g & 1) * 3 * a0.nblocks;
+        a.granules = p.granules2 + (size_t)(g & 1) * GRAN * a0.nblocks;
         a.blk_traj = p.blk_traj2 + (size_t)(g & 1) * a0.nblocks * (a0.N + 1) * 2;
         a.exo_cur = p.exo + (size_t)g * ROVMPC_STATE_LEN;
         a.ring = p.ring; a.seq_theta = p.seq_theta; a.seq_gamma = p.seq_gamma;

@@ -370,8 +370,8 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_consts64, ROVMPC_MAX_CODE * 8));
     CR(hipMalloc(&h->d_Rtab, (size_t)cfg->N * 9 * h->esz));
     CR(hipMalloc(&h->d_k, sizeof(RolloutConsts<double>)));
-    CR(hipMalloc((void **)&h->d_granules, (size_t)3 * max_blocks * sizeof(unsigned long long)));
-    CR(hipMemset(h->d_granules, 0, (size_t)3 * max_blocks * sizeof(unsigned long long)));
+    CR(hipMalloc((void **)&h->d_granules, (size_t)GRAN * max_blocks * sizeof(unsigned long long)));
+    CR(hipMemset(h->d_granules, 0, (size_t)GRAN * max_blocks * sizeof(unsigned long long)));
     h->epoch_ctr = new unsigned(0);
     CR(hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped));
     *h->h_err = 0;
@@ -842,8 +842,8 @@ static int ensure_batch(rovmpc_handle *h, int B) {
     const size_t max_blocks = c.candidates_per_block > 0 ? (size_t)((c.K + c.candidates_per_block - 1) / c.candidates_per_block) : (size_t)c.K;
     HIPCHK(h, hipMalloc(&h->d_Jb, (size_t)B * c.K * h->esz));
     HIPCHK(h, hipMalloc((void **)&h->d_blk_trajb, (size_t)B * max_blocks * (c.N + 1) * 2 * sizeof(double)));
-    HIPCHK(h, hipMalloc((void **)&h->d_granulesb, (size_t)B * 3 * max_blocks * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(h->d_granulesb, 0, (size_t)B * 3 * max_blocks * sizeof(unsigned long long)));
+    HIPCHK(h, hipMalloc((void **)&h->d_granulesb, (size_t)B * GRAN * max_blocks * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_granulesb, 0, (size_t)B * GRAN * max_blocks * sizeof(unsigned long long)));
     h->batch_cap = B;
     return ROVMPC_OK;
 }
@@ -1741,8 +1741,8 @@ static int closed_loop_workspace(rovmpc_handle *h, PersistArgs &p, hipStream_t s
     const size_t max_blocks = c.candidates_per_block > 0 ? (size_t)((c.K + c.candidates_per_block - 1) / c.candidates_per_block) : (size_t)c.K;
     if (!h->d_step_seq) {
         HIPCHK(h, hipMalloc((void **)&h->d_step_seq, 256));
-        HIPCHK(h, hipMalloc((void **)&h->d_cl_granules, 2 * 3 * max_blocks * sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(h->d_cl_granules, 0, 2 * 3 * max_blocks * sizeof(unsigned long long)));
+        HIPCHK(h, hipMalloc((void **)&h->d_cl_granules, 2 * GRAN * max_blocks * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(h->d_cl_granules, 0, 2 * GRAN * max_blocks * sizeof(unsigned long long)));
         HIPCHK(h, hipMalloc((void **)&h->d_cl_blk_traj, 2 * max_blocks * (size_t)(c.N + 1) * 2 * sizeof(double)));
     }
     HIPCHK(h, hipMemsetAsync(h->d_step_seq, 0, 256, s));
@@ -1783,7 +1783,7 @@ static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64
     if (rcw) return rcw;
     // T consecutive epochs tag the granules of the T steps; the tag is never 0 and never repeats within the buffer's life
     if ((unsigned long long)*h->epoch_ctr + (unsigned long long)T_steps + 1 >= 0xffffffffULL) {
-        HIPCHK(h, hipMemsetAsync(h->d_cl_granules, 0, (size_t)2 * 3 * g.nblocks * sizeof(unsigned long long), s));
+        HIPCHK(h, hipMemsetAsync(h->d_cl_granules, 0, (size_t)2 * GRAN * g.nblocks * sizeof(unsigned long long), s));
         *h->epoch_ctr = 0;
     }
     hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
