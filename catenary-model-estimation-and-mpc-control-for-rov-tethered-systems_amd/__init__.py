@@ -17,7 +17,7 @@ from .geometry import (rodrigues_rotation, transform_catenary, transform_catenar
                        kabsch_velocity_transform, compute_rotation_kabsch)
 from .integrate import (SymbolicRegressor, rk4_integration, integrate_theta_gamma, rk4_theta_gamma,
                         integrate_second_order)
-from .features import extract_features, extract_features_arrays, extract_features_host, features_dd, features_dd_arrays, preprocess_signals, compute_derivatives
+from .features import extract_features, extract_features_arrays, features_dd, features_dd_arrays, preprocess_signals, compute_derivatives
 from .lagrangian import euler_lagrange, el_residuals, lagrangian_rollout, differentiate, EulerLagrange
 from .trajgen import generate_rov_trajectories, trajectory_csv
 from .mpc import MPC, GaussianSampler, DeviceGaussianSampler, synthetic_problem

@@ -1,8 +1,7 @@
 """Feature map of generation 1 (simply.py:15-41; main_fun.py:167-193 is the same without the
 two ``_prev`` columns).  ``extract_features`` / ``extract_features_arrays`` run on the GPU
-(``rovmpc_extract_features``); ``extract_features_host`` is the plain NumPy statement kept for
-boxes without a GPU (data preparation only -- it is not on any rollout path).  Inside the
-rollout the same rows are built per (candidate, node) by the fused kernel."""
+(``rovmpc_extract_features``); there is no host restatement in the product (the oracle holds one, for
+the tests).  Inside the rollout the same rows are built per (candidate, node) by the fused kernel."""
 from __future__ import annotations
 
 import numpy as np
@@ -12,26 +11,6 @@ def extract_features_arrays(P0, P1, V1, time, theta, gamma, with_prev: bool = Tr
     """P0, P1 in metres (the reference divides its mm columns by 1000 first), V1 raw.  GPU."""
     from .engine import default_engine
     return default_engine().extract_features(P0, P1, V1, time, theta, gamma, with_prev)
-
-
-def extract_features_host(P0, P1, V1, time, theta, gamma, with_prev: bool = True) -> np.ndarray:
-    """NumPy statement of the same map (no GPU needed)."""
-    P0 = np.asarray(P0, float); P1 = np.asarray(P1, float); V1 = np.asarray(V1, float)
-    time = np.asarray(time, float)
-    A1 = np.stack([np.gradient(V1[:, j], time) for j in range(3)], axis=1)
-    rel_vec = P1 - P0
-    nr = np.linalg.norm(rel_vec, axis=1, keepdims=True)
-    unit_rel = rel_vec / (nr + 1e-8)
-    tension = np.clip(nr, 1e-5, 10)
-    angle_proj = np.clip(np.sum(V1 * unit_rel, axis=1, keepdims=True)
-                         / (np.linalg.norm(V1, axis=1, keepdims=True) + 1e-8), -1, 1)
-    theta = np.asarray(theta, float).reshape(-1, 1); gamma = np.asarray(gamma, float).reshape(-1, 1)
-    cols = [P1, V1, A1, unit_rel, tension, angle_proj, theta, gamma]
-    if with_prev:
-        tp = np.roll(theta, 1); gp = np.roll(gamma, 1)
-        tp[0] = theta[0]; gp[0] = gamma[0]
-        cols += [tp, gp]
-    return np.hstack(cols)
 
 
 def extract_features(df, with_prev: bool = True) -> np.ndarray:
