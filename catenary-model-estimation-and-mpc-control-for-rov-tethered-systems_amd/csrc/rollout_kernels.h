@@ -860,82 +860,92 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); thm0 = ring_get(2); }
             }
-            T th = th0, thm = thm0;
-            if (live && role == 0) RV_PL(sY, 0, 0, c) = th;
-            T x3a = (V0x - m3) * i3;
-            T sinXa = trig.sin(x3a);
+            // Loop-carried values live in two-element arrays indexed by the step's parity p (a literal in each of the two
+            // inlined copies of the step): TH[p] = theta of the previous node, TH[p ^ 1] = theta of this node; X3[p], SX[p] =
+            // x3 and its sine at the step's start; O*[p] = the step's operands, fetched one step ahead into O*[p ^ 1].  A step
+            // writes its results over the values that die with it, so the hand-over to the next step is a renaming, not a
+            // dozen register moves (the optimiser refuses to unroll this loop itself: it holds wave-level votes).
+            T TH[2] = {thm0, th0};
+            if (live && role == 0) RV_PL(sY, 0, 0, c) = th0;
+            T X3[2], SX[2];
+            X3[0] = (V0x - m3) * i3; X3[1] = T(0);
+            SX[0] = trig.sin(X3[0]); SX[1] = T(0);
             // operands of step n, fetched one step ahead (nothing in the loop waits on another wave)
-            T opA = T(0), opB = T(0), opC = T(0), G = T(0);
-            auto fetch = [&](int n) {
-                if (VT == ROVMPC_VT_COMPOSE) { opA = RV_PL(sA, 5, n, c); opB = RV_PL(sA, 6, n, c); opC = RV_PL(sA, 7, n, c); }
-                else opB = RV_PX(0, n + 1, c);
-                G = sG[8 * n + 2];
+            T OA[2] = {T(0), T(0)}, OB[2] = {T(0), T(0)}, OC[2] = {T(0), T(0)}, GG[2] = {T(0), T(0)};
+            auto fetch = [&](int n, int q) {
+                if (VT == ROVMPC_VT_COMPOSE) { OA[q] = RV_PL(sA, 5, n, c); OB[q] = RV_PL(sA, 6, n, c); OC[q] = RV_PL(sA, 7, n, c); }
+                else OB[q] = RV_PX(0, n + 1, c);
+                GG[q] = sG[8 * n + 2];
             };
-            if (nsteps > 0) fetch(0);
-            const bool bounded = s_prog[0] == 0 && Trig<T>::bounded(m_abs(x3a));   // every sine argument of the loop is below the fast-path limit
+            if (nsteps > 0) fetch(0, 0);
+            const bool bounded = s_prog[0] == 0 && Trig<T>::bounded(m_abs(X3[0]));   // every sine argument of the loop is below the fast-path limit
             // sincos(theta_n) for the velocity transform.  theta moves by |d| ~ 1e-4 per step, so
             // after a full evaluation at step 0 (and every 16th step, or whenever a lane's |d|
             // reaches 2^-7) the pair is advanced by the angle-addition formulas with the odd/even
             // Taylor polynomials of d to d^7 / d^8 (truncation < 5e-17).
             T st = T(0), ct = T(1);
-            if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th, &st, &ct);
+            if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th0, &st, &ct);
             // One loop for the common mode (RK4, interpolated delay slot, bounded sine arguments) with its flags
             // as literals, one for everything else with run-time flags.
-            auto run = [&](auto FAST) {
+            auto one_step = [&](auto FAST, auto PAR, int n) {
+                constexpr int p = PAR.value ? 1 : 0, q = p ^ 1;
                 const bool eul = FAST.value ? false : euler, hld = FAST.value ? false : hold, bnd = FAST.value ? true : bounded;
-#pragma unroll 2
-                for (int n = 0; n < nsteps; ++n) {
-                    const T x3b = VT == ROVMPC_VT_COMPOSE ? (opB + opC * ct) + opA * st : opB;
-                    const T Gn = G;
-                    if (n + 1 < nsteps) fetch(n + 1);
-                    const T x3s = x3a + x3b;
-                    const T x3m = x3s / T(2);                                  // :62 feature midpoint
-                    const T sarg = (role & 1) ? x3m : x3b;
-                    const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
-                    T s2r[4];
-                    quad4(s2, s2r);
-                    const T sinXb = s2r[0], sinXm = s2r[1];
-                    // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
-                    const T s16a = (thm - m16) * i16;
-                    T S;
-                    if (eul) {
-                        S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
-                    } else {
-                        const T s16 = hld ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
-                        S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
-                    }
-                    const T thn = th + hKT * S;
-                    if (VT == ROVMPC_VT_COMPOSE) {
-                        // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
-                        // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
-                        const T dlt = thn - th;
-                        const bool big = !(m_abs(dlt) < T(0.0078125));
-                        auto advance = [&]() {
-                            const T d2 = dlt * dlt;
-                            const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
-                            const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
-                            const T sn = st * cd + ct * sd;
-                            ct = ct * cd - st * sd;
-                            st = sn;
-                        };
-                        if (((n + 1) & 15) == 0) {
-                            trig.sincos(thn, &st, &ct);
-                        } else if (!__any(big)) {
-                            advance();
-                        } else {                                   // rare: some lane of the wave took a large step
-                            T fs, fc;
-                            trig.sincos(thn, &fs, &fc);
-                            advance();
-                            if (big) { st = fs; ct = fc; }
-                        }
-                    }
-                    thm = th; th = thn;
-                    x3a = x3b; sinXa = sinXb;
-                    if (live && role == 0) RV_PL(sY, 0, n + 1, c) = th;
-                    // progress word for the early phase-4b batch: one wave's DS operations complete in order,
-                    // so the relaxed store cannot pass the theta store above
-                    if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const T thm = TH[p], th = TH[q], x3a = X3[p], sinXa = SX[p];
+                const T x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
+                const T Gn = GG[p];
+                if (n + 1 < nsteps) fetch(n + 1, q);
+                const T x3s = x3a + x3b;
+                const T x3m = x3s / T(2);                                  // :62 feature midpoint
+                const T sarg = (role & 1) ? x3m : x3b;
+                const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
+                T s2r[4];
+                quad4(s2, s2r);
+                const T sinXb = s2r[0], sinXm = s2r[1];
+                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
+                const T s16a = (thm - m16) * i16;
+                T S;
+                if (eul) {
+                    S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
+                } else {
+                    const T s16 = hld ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
+                    S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
                 }
+                const T thn = th + hKT * S;
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
+                    // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
+                    const T dlt = thn - th;
+                    const bool big = !(m_abs(dlt) < T(0.0078125));
+                    auto advance = [&]() {
+                        const T d2 = dlt * dlt;
+                        const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+                        const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
+                        const T sn = st * cd + ct * sd;
+                        ct = ct * cd - st * sd;
+                        st = sn;
+                    };
+                    if (((n + 1) & 15) == 0) {
+                        trig.sincos(thn, &st, &ct);
+                    } else if (!__any(big)) {
+                        advance();
+                    } else {                                   // rare: some lane of the wave took a large step
+                        T fs, fc;
+                        trig.sincos(thn, &fs, &fc);
+                        advance();
+                        if (big) { st = fs; ct = fc; }
+                    }
+                }
+                TH[p] = thn;                                   // over theta_{n-1}, dead from here
+                X3[q] = x3b; SX[q] = sinXb;
+                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;
+                // progress word for the early phase-4b batch: one wave's DS operations complete in order,
+                // so the relaxed store cannot pass the theta store above
+                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            auto run = [&](auto FAST) {
+                int n = 0;
+                for (; n + 1 < nsteps; n += 2) { one_step(FAST, BoolC<false>{}, n); one_step(FAST, BoolC<true>{}, n + 1); }
+                if (n < nsteps) one_step(FAST, BoolC<false>{}, n);
             };
             if (!euler && !hold && bounded) run(BoolC<true>{}); else run(BoolC<false>{});
             if (tid == 0) __hip_atomic_store(&s_prog[1], N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
