@@ -80,7 +80,7 @@ def build_parser():
     ap.add_argument("--interp", action="store_true", help="force the bytecode interpreter path")
     ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows) | gen2 | gen3")
     ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched ranks may take")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-launched ranks may take")
     ap.add_argument("--fallback-reason", default="", help=argparse.SUPPRESS)   # set by the parent when it re-launches
     return ap
 
