@@ -440,6 +440,35 @@ template <typename T> RV_DEV void dd_surge_sway(T vx, T vy, T vz, T ux, T uy, T 
     sway = m_sqrt(cx * cx + cy * cy + cz * cz);
 }
 
+// ---- counter-based normals (the proposal law of MPC.step with device sampling; util_kernels.h states the law) ---------
+RV_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// the four standard normals of block j: Philox4x32-10(counter (j lo, j hi, step lo, step hi), key (seed lo, seed hi)),
+// u_i = (x_i + 0.5) 2^-32, two Box-Muller pairs.  One routine for the stand-alone sampler and for the rollout kernel that
+// draws its candidates itself, so that both produce the same bits.
+RV_DEV void philox_normal4(unsigned long long seed, unsigned long long step, long long j, double (&z)[4]) {
+    unsigned x[4];
+    philox4x32_10((unsigned)j, (unsigned)((unsigned long long)j >> 32), (unsigned)step, (unsigned)(step >> 32),
+                  (unsigned)seed, (unsigned)(seed >> 32), x);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double u1 = ((double)x[2 * h] + 0.5) * 2.3283064365386963e-10, u2 = ((double)x[2 * h + 1] + 0.5) * 2.3283064365386963e-10;
+        const double r = ::sqrt(-2.0 * ::log(u1));
+        double sn, cs;
+        m_sincos(6.283185307179586 * u2, &sn, &cs);
+        z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
+    }
+}
+
 // order-preserving double <-> int64 map (signed compare of keys == IEEE compare of values)
 RV_DEV long long ordered_key(double v) {
     long long b = __double_as_longlong(v);

@@ -112,6 +112,17 @@ template <typename T> struct RolloutArgs {
     long long k_offset;
     int rank, world;
     unsigned long long *stamps;   // diagnostic build only (-DROVMPC_STAMPS): [nblocks][16] 100 MHz ticks
+    // Fused sampling (rollout_kernel_sampled, rovmpc_mpc_step_sampled with the compiled-in model): the candidates are DRAWN in
+    // phase 0 -- block j of four normals = philox_normal4(seed, step, j), the law of sample_candidates_kernel -- instead of
+    // being read: the candidate tensor never exists in HBM, the state arrives as a kernel argument, and the sweeper
+    // re-draws the winner's sequence into samp_best (the next step's warm start; the record's u).  Appended at the end
+    // of the struct: the other instantiations' argument offsets do not move.
+    unsigned long long samp_seed, samp_step;
+    double samp_mean[3], samp_std[3];
+    const double *samp_warm;      // previous winner's sequence [N][3] (null: no warm start)
+    double *samp_best;            // [N][3]: this step's winner's sequence
+    double *samp_blk_u;           // [nblocks][3 N]: every workgroup's best candidate's controls, handed over like its trajectory
+    double samp_state[ROVMPC_STATE_LEN];
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -201,7 +212,7 @@ RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __AT
 // order-preserving int64 image of the record into slots[rank][*] and INT64_MAX elsewhere
 // (input of the single all-reduce(min) of the candidate-sharded step).  `scratch` = 16
 // doubles of LDS.
-template <typename T, bool LEAN = false>
+template <typename T, bool LEAN = false, bool SAMPLE = false>
 RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *granules, const double *blk_traj, const T *U,
                             double *result, double *scratch) {
     const int nblocks = a.nblocks, N = a.N, CK = a.CK, NT = a.NT, rank = a.rank, world = a.world;
@@ -281,6 +292,13 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) st_agent(a.seq_theta, (unsigned long long)(a.step + 1));
     }
+    if (SAMPLE) {
+        // the winner's control sequence (its workgroup handed it over with the trajectory): the record's u and the next
+        // step's warm start
+        const double *bu = a.samp_blk_u + (size_t)(kbest / CK) * 3 * N;
+        for (int j = tid; j < 3 * N; j += NT) a.samp_best[j] = ld_agent(&bu[j]);
+        __syncthreads();
+    }
     bool row_free = true;
     if (!LEAN && a.flag_consumed) {
         // the slot buffer is reused every few steps: its previous contents must have been read by that step's select.
@@ -304,7 +322,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         double v;
         if (i == 0) v = row_free ? Jbest : __builtin_nan("");
         else if (i == 1) v = (double)(kbest + a.k_offset);
-        else if (i < 5) v = (double)U[(size_t)kbest * N * 3 + (i - 2)];
+        else if (i < 5) v = SAMPLE ? a.samp_best[i - 2] : (double)U[(size_t)kbest * N * 3 + (i - 2)];
         else v = ld_agent(&bt[i - 5]);
         result[i] = v;
         if (!LEAN && a.result_host) a.result_host[i] = v;
@@ -409,7 +427,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 // LEAN: the plain single-problem step (rovmpc_step_device and the host-pointer entry points): one problem, no slot image,
 // no hand-off flags, no host mirror, no plant update -- those branches are compiled out (measured on one box: the full
 // kernel is 0.3 us slower per C2 step than the round-1 kernel, which had none of them).
-template <typename T, int MODEL, int VT, bool PERSIST = false, bool LEAN = false>
+template <typename T, int MODEL, int VT, bool PERSIST = false, bool LEAN = false, bool SAMPLE = false>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -459,7 +477,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
     // (closed loop with GPU-side hand-off: the measured row of this step stands in for the state; theta / gamma arrive
     // later, in the waves that need them -- ring_wait / ring_get)
-    const double *sdg = PERSIST ? a.exo_cur : a.state + (size_t)prob * ROVMPC_STATE_LEN;
+    const double *sdg = SAMPLE ? a.samp_state : (PERSIST ? a.exo_cur : a.state + (size_t)prob * ROVMPC_STATE_LEN);
     auto sd_at = [&](int i) -> double { return sdg[i]; };
     // Whole-wave call: lane 0 polls the sequence word until the record of this step is out (bounded: on giving up it raises
     // the error word and the wave goes on with whatever the ring holds).
@@ -558,7 +576,32 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const int tot = nvalid * N * 3;
         constexpr int VW = 16 / sizeof(T);           // elements per 16-byte lane load
         const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (tot % VW == 0);
-        if (vec) {
+        if (SAMPLE) {
+            // draw the chunk: element e = (k N + n) 3 + c of the candidate tensor is mean[c] + std[c] z_e; a lane takes whole
+            // Philox blocks (four consecutive elements) and keeps those that fall into this workgroup's chunk
+            const long long e_lo = (long long)k0 * N * 3, e_hi = e_lo + tot;
+            const long long jb_lo = e_lo >> 2, jb_hi = (e_hi + 3) >> 2;
+            for (long long jb = jb_lo + ltid; jb < jb_hi; jb += LNT) {
+                double z[4];
+                philox_normal4(a.samp_seed, a.samp_step, jb, z);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long e = 4 * jb + q;
+                    if (e < e_lo || e >= e_hi) continue;
+                    const int g = (int)(e - e_lo), c = (int)__umulhi((unsigned)g, a.magic_3n), j = g - c * (3 * N), cc = j % 3;
+                    T v = (T)::fma(a.samp_std[cc], z[q], a.samp_mean[cc]);
+                    if (a.samp_warm && e < 3 * N) {          // candidate 0: the previous winner shifted by one step
+                        const int n = j / 3, sn = n + 1 < N ? n + 1 : N - 1;
+                        v = (T)a.samp_warm[3 * sn + cc];
+                    }
+                    sU[c * US + j] = v;
+                }
+            }
+            for (int i = tot + ltid; i < CK * N * 3; i += LNT) {
+                const int c = (int)__umulhi((unsigned)i, a.magic_3n), j = i - c * (3 * N);
+                sU[c * US + j] = T(0);
+            }
+        } else if (vec) {
             typedef T vecT __attribute__((ext_vector_type(VW)));
             const vecT *src4 = reinterpret_cast<const vecT *>(src);
             for (int i = ltid; i < tot / VW; i += LNT) {
@@ -1532,6 +1575,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 st_agent(&bt[2 * c], (double)RV_PL(sY, 0, c, cb));
                 st_agent(&bt[2 * c + 1], (double)RV_PL(sY, 1, c, cb));
             }
+            if (SAMPLE) {
+                double *bu = a.samp_blk_u + (size_t)blockIdx.x * 3 * N;
+                for (int j = c; j < 3 * N; j += 64) st_agent(&bu[j], (double)sU[cb * US + j]);
+            }
             if (c == 0) publish_best(granb, a.nblocks, a.epoch, Jd, (unsigned)cb);     // the cost does not wait for the drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (c == 0) publish_traj_ready(granb, a.nblocks, a.epoch);
@@ -1548,6 +1595,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         for (int i = tid; i < (N + 1); i += NT) {
             st_agent(&bt[2 * i], (double)RV_PL(sY, 0, i, cb));
             st_agent(&bt[2 * i + 1], (double)RV_PL(sY, 1, i, cb));
+        }
+        if (SAMPLE) {
+            double *bu = a.samp_blk_u + (size_t)blockIdx.x * 3 * N;
+            for (int j = tid; j < 3 * N; j += NT) st_agent(&bu[j], (double)sU[cb * US + j]);
         }
         if (trajb) {
             for (int i = tid; i < nvalid * (N + 1); i += NT) {
@@ -1576,6 +1627,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
     } else if (LEAN) {
         argmin_epilogue<T, true>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
+    } else if (SAMPLE) {
+        argmin_epilogue<T, false, true>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
     } else {
         // The epilogue's own arguments (hand-off flags, slot buffer, plant update, host mirror ...) are cold: one workgroup
         // reads them once.  Read here through the kernarg segment pointer made opaque, their scalar loads cannot be
@@ -1602,6 +1655,12 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel_lean(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT, false, true>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_sampled(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, false, true>(a);
 }
 
 // ---- persistent closed loop --------------------------------------------------------------------------------------

@@ -76,6 +76,10 @@ struct rovmpc_handle {
     double *h_record = nullptr, *d_record_host = nullptr;
     unsigned long long *h_done = nullptr, *d_done = nullptr;
     unsigned long long samp_steps = 0;
+    double *d_best = nullptr;                    // [2][N][3]: winner's sequence of the last fused-sampling steps, by step parity
+    double *d_blk_u = nullptr;                   // [max_blocks][3 N]: per-workgroup best controls of a fused-sampling step
+    // what the last sampled step drew with (rovmpc_sampled_candidates re-draws the tensor for inspection)
+    unsigned long long last_seed = 0, last_step = 0; double last_mean[3] = {}, last_std[3] = {}; int last_warm = 0; bool last_fused = false;
     double *arg_result_host = nullptr; unsigned long long *arg_done_flag = nullptr; unsigned long long arg_done_seq = 0;
     // batched launches: workspace for `batch_cap` problems
     int batch_cap = 0;
@@ -395,7 +399,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
-                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj};
+                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj, h->d_best, h->d_blk_u};
     for (auto &ev : h->pipe_ev) if (ev) (void)hipEventDestroy(ev);
     if (h->h_record) (void)hipHostFree(h->h_record);
     if (h->h_done) (void)hipHostFree(h->h_done);
@@ -740,6 +744,7 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.NT = g.NT; a.nblocks = g.nblocks;
     a.plant_next = h->plant_next; a.plant_state = h->plant_state; a.plant_feedback = h->plant_feedback;
     a.ring = nullptr; a.exo_cur = nullptr; a.seq_theta = nullptr; a.seq_gamma = nullptr;
+    a.samp_seed = 0; a.samp_step = 0; a.samp_warm = nullptr; a.samp_best = nullptr; a.samp_blk_u = nullptr;
     a.step = 0; a.from_ring = 0; a.wait_theta = 0; a.publish = 0;
     a.result_host = h->arg_result_host; a.done_flag = h->arg_done_flag; a.done_seq = h->arg_done_seq;
     a.flag_consumed = h->arg_flag_consumed; a.flag_rolled = h->arg_flag_rolled;
@@ -883,14 +888,14 @@ static int ensure_sampler(rovmpc_handle *h) {
 }
 
 static int launch_sampler(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step, const double *mean3,
-                          const double *std3, int warm, void *d_U, const void *d_Uprev, hipStream_t s) {
+                          const double *std3, int warm, void *d_U, const void *d_Uprev, hipStream_t s, const double *warm_seq = nullptr) {
     SampleArgs sa;
     memset(&sa, 0, sizeof(sa));
     if (state) { sa.state = *state; sa.d_state = h->d_state; }
     sa.seed = seed; sa.step = step;
     for (int i = 0; i < 3; ++i) { sa.mean[i] = mean3[i]; sa.std[i] = std3[i]; }
     sa.total = (long long)h->cfg.K * h->cfg.N * 3; sa.N = h->cfg.N;
-    sa.warm = warm; sa.Uprev = d_Uprev; sa.prev_record = h->d_result;
+    sa.warm = warm; sa.Uprev = d_Uprev; sa.prev_record = h->d_result; sa.warm_seq = warm_seq;
     const int bs = 256;
     const int grid = (int)(((sa.total + 3) / 4 + bs - 1) / bs);
     if (h->cfg.dtype == ROVMPC_F64) hipLaunchKernelGGL(sample_candidates_kernel<double>, dim3(grid), dim3(bs), 0, s, sa, (double *)d_U);
@@ -908,6 +913,42 @@ extern "C" int rovmpc_sample_candidates_device(rovmpc_handle *h, uint64_t seed, 
     return launch_sampler(h, nullptr, seed, step, mean3, std3, 0, d_U, nullptr, (hipStream_t)stream);
 }
 
+// Compiled-in model: the rollout kernel draws its candidates itself (rollout_kernel_sampled) -- no sampler launch, no
+// candidate tensor, the state in the kernel arguments.
+template <typename T, int VT>
+static hipError_t launch_sampled(const rovmpc_handle *h, const RolloutArgs<T> &a, hipStream_t s) {
+    const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
+    auto kern = rollout_kernel_sampled<T, MODEL_BUILTIN, VT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(a.NT), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static int fused_sampled_step_t(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step, const double *mean3,
+                                const double *std3, int warm, unsigned long long seq) {
+    const int cur = (int)(h->samp_steps & 1);
+    const size_t row = (size_t)h->cfg.N * 3;
+    RolloutArgs<T> a;
+    const Geo g = launch_geometry(h, 1);
+    fill_args<T>(h, a, h->d_state, nullptr, nullptr, g, 1);
+    a.result = h->d_result; a.k_offset = 0; a.slots = nullptr; a.rank = 0; a.world = 1;
+    a.result_host = h->d_record_host; a.done_flag = h->d_done; a.done_seq = seq;
+    a.samp_seed = seed; a.samp_step = step;
+    for (int i = 0; i < 3; ++i) { a.samp_mean[i] = mean3[i]; a.samp_std[i] = std3[i]; }
+    a.samp_warm = warm ? h->d_best + (size_t)(cur ^ 1) * row : nullptr;
+    a.samp_best = h->d_best + (size_t)cur * row;
+    a.samp_blk_u = h->d_blk_u;
+    memcpy(a.samp_state, state, sizeof(a.samp_state));
+    const int vt = h->cfg.vt_mode;
+    hipError_t e = vt == 0 ? launch_sampled<T, 0>(h, a, h->stream) : vt == 1 ? launch_sampled<T, 1>(h, a, h->stream) : launch_sampled<T, 2>(h, a, h->stream);
+    if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "fused sampling launch failed: %s", hipGetErrorString(e));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *state, uint64_t seed, uint64_t step,
                                        const double *mean3, const double *std3, int32_t warm_start, double *record_out) {
     if (!h) return ROVMPC_ERR_INVALID;
@@ -918,12 +959,28 @@ extern "C" int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *sta
     if ((rc = ensure_sampler(h))) return rc;
     const int cur = (int)(h->samp_steps & 1);
     const int warm = warm_start && h->samp_steps > 0;
+    const bool fused = h->model_kind == MODEL_BUILTIN && (h->samp_steps == 0 || h->last_fused) && !h->timing;
+    h->last_seed = seed; h->last_step = step; h->last_warm = warm; h->last_fused = fused;
+    for (int i = 0; i < 3; ++i) { h->last_mean[i] = mean3[i]; h->last_std[i] = std3[i]; }
+    unsigned long long seq = h->samp_steps + 1;
+    if (fused) {
+        if (!h->d_best) {
+            const size_t max_blocks = h->cfg.candidates_per_block > 0 ? (size_t)((h->cfg.K + h->cfg.candidates_per_block - 1) / h->cfg.candidates_per_block) : (size_t)h->cfg.K;
+            HIPCHK(h, hipMalloc((void **)&h->d_best, (size_t)2 * h->cfg.N * 3 * sizeof(double)));
+            HIPCHK(h, hipMalloc((void **)&h->d_blk_u, max_blocks * (size_t)h->cfg.N * 3 * sizeof(double)));
+        }
+        rc = h->cfg.dtype == ROVMPC_F64 ? fused_sampled_step_t<double>(h, state, seed, step, mean3, std3, warm, seq)
+                                        : fused_sampled_step_t<float>(h, state, seed, step, mean3, std3, warm, seq);
+        ++h->samp_steps;
+        if (rc) return rc;
+    } else {
     if ((rc = launch_sampler(h, state, seed, step, mean3, std3, warm, h->d_Us[cur], h->d_Us[cur ^ 1], h->stream))) return rc;
-    const unsigned long long seq = ++h->samp_steps;
+    seq = ++h->samp_steps;
     h->arg_result_host = h->d_record_host; h->arg_done_flag = h->d_done; h->arg_done_seq = seq;
     rc = enqueue_step(h, h->d_state, h->d_Us[cur], nullptr, h->d_result, 0, nullptr, 0, 1, h->stream);
     h->arg_result_host = nullptr; h->arg_done_flag = nullptr;
     if (rc) return rc;
+    }
     // the sweeper releases `seq` into mapped host memory behind the record: spin on it (a stream synchronise costs
     // several microseconds of wake-up latency); after ~2 s fall back to the blocking call so a failed launch is reported
     const auto t0 = std::chrono::steady_clock::now();
@@ -944,7 +1001,16 @@ extern "C" int rovmpc_sampled_candidates(rovmpc_handle *h, void *U_out) {
     if (!U_out || h->samp_steps == 0) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_sampled_candidates: no sampled step yet");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(U_out, h->d_Us[(h->samp_steps - 1) & 1], (size_t)h->cfg.K * h->cfg.N * 3 * h->esz, hipMemcpyDeviceToHost));
+    const int cur = (int)((h->samp_steps - 1) & 1);
+    if (h->last_fused) {
+        // the fused step never stored its tensor: draw it again with the stand-alone sampler (same routine, same bits),
+        // warm start from the previous winner's sequence, which the step left untouched
+        const double *warm_seq = h->last_warm ? h->d_best + (size_t)(cur ^ 1) * h->cfg.N * 3 : nullptr;
+        int rc = launch_sampler(h, nullptr, h->last_seed, h->last_step, h->last_mean, h->last_std, h->last_warm, h->d_Us[cur], nullptr, h->stream, warm_seq);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipMemcpy(U_out, h->d_Us[cur], (size_t)h->cfg.K * h->cfg.N * 3 * h->esz, hipMemcpyDeviceToHost));
     return ROVMPC_OK;
 }
 

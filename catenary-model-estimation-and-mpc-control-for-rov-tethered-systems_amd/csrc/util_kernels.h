@@ -13,17 +13,6 @@ namespace rovmpc {
 // The test oracle restates exactly this law (philox_normals), so a step is reproducible on the host.
 // warm != 0: candidate 0 is the previous winner shifted by one step, U[0][n] = Uprev[k*][min(n + 1, N - 1)], k* read
 // from the previous record on the device.  The state crosses as a kernel argument (no H2D copy on the step path).
-RV_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned *out) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 struct SampleArgs {
     rovmpc_state state;                 // written to d_state by block 0 (null d_state: not written)
     double *d_state;
@@ -33,6 +22,7 @@ struct SampleArgs {
     int N, warm;
     const void *Uprev;                  // previous candidate tensor (warm start source)
     const double *prev_record;          // previous record: [1] = k*
+    const double *warm_seq;             // or: the previous winner's sequence [N][3] itself (then Uprev / prev_record are unused)
 };
 
 template <typename T>
@@ -42,30 +32,20 @@ sample_candidates_kernel(const SampleArgs a, T *__restrict__ U) {
         a.d_state[threadIdx.x] = reinterpret_cast<const double *>(&a.state)[threadIdx.x];
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x, e0 = 4 * j;
     if (e0 >= a.total) return;
-    unsigned x[4];
-    philox4x32_10((unsigned)j, (unsigned)((unsigned long long)j >> 32), (unsigned)a.step, (unsigned)(a.step >> 32),
-                  (unsigned)a.seed, (unsigned)(a.seed >> 32), x);
     double z[4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const double u1 = ((double)x[2 * h] + 0.5) * 2.3283064365386963e-10, u2 = ((double)x[2 * h + 1] + 0.5) * 2.3283064365386963e-10;
-        const double r = ::sqrt(-2.0 * ::log(u1));
-        double sn, cs;
-        m_sincos(6.283185307179586 * u2, &sn, &cs);
-        z[2 * h] = r * cs; z[2 * h + 1] = r * sn;
-    }
+    philox_normal4(a.seed, a.step, j, z);
     const int row3 = 3 * a.N;
-    const long long kprev = (a.warm && e0 < row3) ? (long long)a.prev_record[1] : 0;
+    const long long kprev = (a.warm && !a.warm_seq && e0 < row3) ? (long long)a.prev_record[1] : 0;
     const T *Up = reinterpret_cast<const T *>(a.Uprev);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long long e = e0 + i;
         if (e >= a.total) break;
         const int c = (int)(e % 3);
-        T v = (T)(a.mean[c] + a.std[c] * z[i]);
+        T v = (T)::fma(a.std[c], z[i], a.mean[c]);
         if (a.warm && e < row3) {                       // candidate 0: shifted previous optimum
             const int n = (int)(e / 3), src = n + 1 < a.N ? n + 1 : a.N - 1;
-            v = Up[kprev * row3 + 3 * src + c];
+            v = a.warm_seq ? (T)a.warm_seq[3 * src + c] : Up[kprev * row3 + 3 * src + c];
         }
         U[e] = v;
     }

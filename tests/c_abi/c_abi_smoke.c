@@ -47,6 +47,34 @@ int main(void) {
     for (int i = 1; i < cfg.K; ++i) if (J[i] < J[k]) k = i;
     if (k != idx || J[k] != best || u[0] != U[(size_t)k * cfg.N * 3]) { fprintf(stderr, "arg-min mismatch: %d vs %lld\n", k, (long long)idx); return 1; }
     if (traj[0] != st.theta || traj[1] != st.gamma) { fprintf(stderr, "trajectory does not start at the state\n"); return 1; }
+
+    /* round-2 entry points, still plain C: one control step with the candidates drawn on the GPU (same (seed, step) ->
+     * same record; the tensor can be fetched and its arg-min must be the record's), a program evaluated on rows
+     * (the Euler-Lagrange residual 2 x4 of L = x2^2 + x3^2), the handle's error word */
+    const double mean3[3] = {0.0, 0.0, 0.0}, std3[3] = {2.0, 2.0, 2.0};
+    const int R = rovmpc_result_len(h);
+    double *rec = malloc(sizeof(double) * R), *rec2 = malloc(sizeof(double) * R);
+    CHECK(h, rovmpc_mpc_step_sampled(h, &st, 7u, 0u, mean3, std3, 0, rec));
+    CHECK(h, rovmpc_sampled_candidates(h, U));
+    CHECK(h, rovmpc_rollout_costs(h, &st, U, J, NULL));
+    k = 0;
+    for (int i = 1; i < cfg.K; ++i) if (J[i] < J[k]) k = i;
+    if ((int)rec[1] != k || rec[0] != J[k] || rec[2] != U[(size_t)k * cfg.N * 3]) { fprintf(stderr, "sampled step: arg-min mismatch\n"); return 1; }
+    rovmpc_handle *h2 = NULL;
+    CHECK(NULL, rovmpc_create(&cfg, &h2));
+    CHECK(h2, rovmpc_set_model(h2, 18, mean, scale, th, 8, ga, 3, consts, 1));
+    CHECK(h2, rovmpc_mpc_step_sampled(h2, &st, 7u, 0u, mean3, std3, 0, rec2));
+    for (int i = 0; i < R; ++i) if (rec[i] != rec2[i]) { fprintf(stderr, "sampled step is not a function of (state, seed, step)\n"); return 1; }
+    rovmpc_destroy(h2);
+    const double two[1] = {2.0};
+    const int32_t eom[] = {(0 << 8) | ROVMPC_OP_PUSH_C, (4 << 8) | ROVMPC_OP_PUSH_F, ROVMPC_OP_MUL};
+    const double rows[2 * 6] = {0.1, 0.2, 0.3, 0.4, -1.5, 0.6, 0, 0, 0, 0, 0.25, 0};
+    double res[2];
+    CHECK(h, rovmpc_eval_expression(h, eom, 3, two, 1, rows, 6, 2, res));
+    if (res[0] != -3.0 || res[1] != 0.5) { fprintf(stderr, "eval_expression: %g %g\n", res[0], res[1]); return 1; }
+    CHECK(h, rovmpc_device_status(h));
+    if (rovmpc_set_option(h, "no_such_option", 1.0) != ROVMPC_ERR_INVALID) { fprintf(stderr, "unknown option accepted\n"); return 1; }
+    free(rec); free(rec2);
     printf("c_abi_smoke ok: k*=%lld J*=%.12g u=(%.6f %.6f %.6f)\n", (long long)idx, best, u[0], u[1], u[2]);
     free(U); free(J);
     rovmpc_destroy(h);

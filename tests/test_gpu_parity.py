@@ -1055,12 +1055,24 @@ def test_lagrangian_residuals_and_rollout(rv, orc, golden_dir):
         rv.lagrangian_rollout("0.5*x2**2 + 0.5*x3**2 + 0.3*x2*x3*cos(x0)", g["synth_time"], 0.1, 0.1, 0.0, 0.0)
 
 
-def test_mpc_step_with_device_side_sampling(rv, orc):
+@pytest.mark.parametrize("fused", [True, False])
+def test_mpc_step_with_device_side_sampling(rv, orc, fused):
     """MPC(device_sampling=True): one library call per step draws the candidates on the GPU (Philox4x32-10 + Box-Muller),
     rolls them out and returns the record.  The tensor is exactly the oracle's restatement of the law for (seed, step);
-    the returned control is the arg-min of those candidates; warm start pins candidate 0; fp32 too."""
+    the returned control is the arg-min of those candidates; warm start pins candidate 0; fp32 too.  fused: the compiled-in
+    kernel draws its candidates itself (no tensor in HBM); otherwise (any other model path) sampler kernel + rollout kernel."""
     import time
-    mpc = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    if not fused:
+        _orig = rv.MPC
+        class _M(_orig):                                   # same rows through hiprtc: the two-kernel path
+            def __init__(self, *a, **kw):
+                kw["no_builtin"] = True
+                super().__init__(*a, **kw)
+        MPC = _M
+    else:
+        MPC = rv.MPC
+    mpc = MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    assert mpc.engine.model_path == ("builtin" if fused else "jit")
     state, _ = rv.synthetic_problem(256, 12)
     model = rv.default_model()
     u = mpc.step(state)
@@ -1080,13 +1092,13 @@ def test_mpc_step_with_device_side_sampling(rv, orc):
     Jo2, _, _ = orc.rollout_vec(oracle_cfg(orc, mpc.cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U2)
     assert mpc.last.index == int(np.argmin(Jo2)) and np.array_equal(u2, U2[mpc.last.index, 0])
     # the same (seed, step) gives the same step on a fresh controller; another seed does not
-    mpc_b = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    mpc_b = MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
     assert np.array_equal(mpc_b.step(state), u)
-    mpc_c = rv.MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=100))
+    mpc_c = MPC(N=12, K=256, device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=100))
     mpc_c.step(state)
     assert not np.array_equal(mpc_c.engine.sampled_candidates(), U)
     # fp32 tensor: the fp64 draw rounded once
-    mpc_f = rv.MPC(N=12, K=256, dtype="f32", device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
+    mpc_f = MPC(N=12, K=256, dtype="f32", device_sampling=True, sampler=rv.DeviceGaussianSampler(seed=99))
     mpc_f.step(state)
     np.testing.assert_allclose(mpc_f.engine.sampled_candidates(), Uo.astype(np.float32), rtol=2e-7, atol=1e-5)
     # the stand-alone sampler entry fills a caller's device tensor with the same law
@@ -1096,7 +1108,7 @@ def test_mpc_step_with_device_side_sampling(rv, orc):
     torch.cuda.synchronize()
     assert np.array_equal(dU.cpu().numpy(), U)
     # the host never touches the candidate tensor: a C2-sized step costs little more than its kernels
-    mpc_big = rv.MPC(N=20, K=4096, device_sampling=True)
+    mpc_big = MPC(N=20, K=4096, device_sampling=True)
     st, _ = rv.synthetic_problem(1, 20)
     for _ in range(20):
         mpc_big.step(st)
@@ -1104,7 +1116,7 @@ def test_mpc_step_with_device_side_sampling(rv, orc):
     for _ in range(200):
         mpc_big.step(st)
     per_step = (time.perf_counter() - t0) / 200
-    assert per_step < 60e-6, per_step                                             # measured ~30 us; the bar leaves room for a busy host
+    assert per_step < (60e-6 if fused else 90e-6), per_step                                             # measured ~30 us; the bar leaves room for a busy host
     for m in (mpc, mpc_b, mpc_c, mpc_f, mpc_big):
         m.close()
 
