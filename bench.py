@@ -121,13 +121,19 @@ def _run_ranks(argv, n, timeout):
 
 
 def launch_ranks(args, argv):
-    rc, line, out = _run_ranks(argv, args.gpus, args.launch_timeout)
-    if (rc != 0 or line is None) and rc != 124 and not args.torch_collective and not args.protocol_only and args.backend == "nccl":
-        # the library's own RCCL path failed as a whole (a rank died): one more run on torch.distributed's
-        # collective, with the reason carried into the JSON line -- never a silent switch
-        why = f"native RCCL run exited with code {rc}" + ("" if line else " without a result line")
+    native = not args.torch_collective and not args.protocol_only and args.backend == "nccl"
+    # the library's own RCCL path has never run at world > 1 (RCCL refuses two ranks on the one GPU of the build box):
+    # it gets a bounded first attempt; if it dies OR does not finish, its whole process group is killed and the run is
+    # repeated once on torch.distributed's collective, with the reason carried into the JSON line -- never a silent switch
+    t_first = min(args.launch_timeout, 300.0) if native else args.launch_timeout
+    t0 = time.time()
+    rc, line, out = _run_ranks(argv, args.gpus, t_first)
+    if (rc != 0 or line is None) and native:
+        why = (f"native RCCL run did not finish within {t_first:.0f} s" if rc == 124 else f"native RCCL run exited with code {rc}") + \
+              ("" if line else " without a result line")
         print(f"[bench] {why}; re-running with --torch-collective", file=sys.stderr)
-        rc, line, out = _run_ranks(argv + ["--torch-collective", "--fallback-reason", why], args.gpus, args.launch_timeout)
+        left = max(120.0, args.launch_timeout - (time.time() - t0))
+        rc, line, out = _run_ranks(argv + ["--torch-collective", "--fallback-reason", why], args.gpus, left)
     if line is None:
         sys.stderr.write(out[-4000:])
         print(f"[bench] ranks produced no result line (exit code {rc})", file=sys.stderr)
