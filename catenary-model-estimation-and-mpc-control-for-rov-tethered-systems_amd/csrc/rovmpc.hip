@@ -82,7 +82,7 @@ struct rovmpc_handle {
     unsigned long long last_seed = 0, last_step = 0; double last_mean[3] = {}, last_std[3] = {}; int last_warm = 0; bool last_fused = false;
     double *arg_result_host = nullptr; unsigned long long *arg_done_flag = nullptr; unsigned long long arg_done_seq = 0;
     // batched launches: workspace for `batch_cap` problems
-    int batch_cap = 0;
+    int batch_cap = 0, last_batch = 1;
     void *d_Jb = nullptr; double *d_blk_trajb = nullptr; unsigned long long *d_granulesb = nullptr;
     const double *plant_next = nullptr;       // closed loop: plant update fused into the step being enqueued
     double *plant_state = nullptr;
@@ -825,6 +825,7 @@ static int enqueue_step(rovmpc_handle *h, const double *d_state, const void *d_U
                        ? launch_rollout_t<double>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s, B)
                        : launch_rollout_t<float>(h, d_state, d_U, d_traj_all, d_result, k_offset, d_slots, rank, world, s, B);
     if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
+    h->last_batch = B;
     if (time_it) { HIPCHK(h, hipEventRecord(h->ev[h->ev_used + 1], s)); h->ev_used += 2; }
     return ROVMPC_OK;
 }
@@ -867,7 +868,7 @@ extern "C" int rovmpc_step_batch_device(rovmpc_handle *h, int32_t B, const doubl
 
 extern "C" int rovmpc_batch_costs_device(rovmpc_handle *h, const void **d_J) {
     if (!h || !d_J) return ROVMPC_ERR_INVALID;
-    *d_J = h->batch_cap > 0 ? h->d_Jb : h->d_J;
+    *d_J = h->last_batch > 1 ? h->d_Jb : h->d_J;        // where the last launch on this handle wrote its costs
     return ROVMPC_OK;
 }
 
@@ -1936,9 +1937,11 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
         if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
     } else if (h->model_kind == MODEL_JIT) {
         if (!h->jit_fn_step) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the run-time specialised module has no pipelined entry");
-        capacity = 2 * g.nblocks <= 2 * h->n_cu ? 2 * h->n_cu : 0;   // one 16-candidate workgroup per CU and launch: two fit a CU's LDS / wave slots
         const size_t lds = rollout_lds_elems<T>(h->cfg.N, g.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
-        if (lds > 80 * 1024) capacity = 0;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->jit_fn_step, g.NT, lds) != hipSuccess) per_cu = 0;
+        capacity = per_cu * h->n_cu;
     } else {
         FAIL(h, ROVMPC_ERR_UNSUPPORTED, "pipelined closed loop: compiled-in and hiprtc-specialised models only (the interpreter runs launch per step)");
     }
