@@ -920,6 +920,32 @@ def test_persistent_closed_loop_refuses_what_it_cannot_hold(rv):
             run_closed_loop(e, 12, 10, persistent=True)
 
 
+def test_bench_two_ranks_on_one_gpu_over_gloo(rv):
+    """The N > 1 step with real kernels and two real processes: `bench.py --gpus 2 --backend gloo --devices 0,0` starts its
+    own two ranks, both on GPU 0 (RCCL refuses a shared GPU, so the slot image crosses the host through gloo); every rank
+    must end with the same global record, and it must be the arg-min over both shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--devices", "0,0",
+                        "--steps", "30", "--warmup", "5", "--K", "1024", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_agree"] is True and d["config"]["K_global"] == 2048
+    # the same 2 x 1024 candidates un-sharded on one handle: rank r's last batch is pool (steps - 1) % 8 of seed 20250523 + 1000 r + p
+    pidx = (30 - 1) % 8
+    state, _ = rv.synthetic_problem(1, 20)
+    U = np.concatenate([rv.synthetic_problem(1024, 20, seed=20250523 + 1000 * r + pidx)[1] for r in range(2)])
+    with rv.Engine(rv.MPCConfig(N=20, K=2048)) as e:
+        want = e.step(state, U)
+    assert d["best"]["index"] == want.index and d["best"]["cost"] == want.cost
+
+
 def test_handoff_timeouts_are_errors_not_wrong_records(rv):
     """The sharded step's GPU-side waits (collective <- rollout row, rollout <- select that frees the slot row) give up
     after handoff_timeout_ms.  A give-up must surface as an error of the synchronising call and a NaN cost in the affected
