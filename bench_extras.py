@@ -137,6 +137,11 @@ def run_extras(out, args, cfg, model, dev):
                                   "final_cost": float(rep.cost[-1])}
                 except rovmpc.RovmpcError as exc:
                     runs[mode] = {"error": str(exc)}
+            if not feedback:
+                run_closed_loop(eng3, 12, 200, feedback=False, mode="batched")
+                rep = run_closed_loop(eng3, 12, T, feedback=False, mode="batched")
+                runs["batched_replay"] = {"us_per_step": 1e6 * rep.wall_s / rep.steps, "real_time_factor": rep.real_time_factor,
+                                          "final_cost": float(rep.cost[-1]), "problems_per_launch": 8}
             table["feedback" if feedback else "measured_rows"] = runs
         fb = table["feedback"]
         best = min((m for m in fb if "us_per_step" in fb[m]), key=lambda m: fb[m]["us_per_step"], default=None)
@@ -147,5 +152,6 @@ def run_extras(out, args, cfg, model, dev):
                                       "10 000 fed-back steps: costs grow, parity is the bar, not plausibility); measured_rows: every step "
                                       "takes its whole state from the trajectory table.  per_step = one launch per step on one stream; "
                                       "pipelined = one launch per step on two streams with the state handed over on the GPU; persistent = "
-                                      "one launch for all steps.  real_time_factor = steps * dt / wall"}
+                                      "one launch for all steps; batched_replay (measured rows only) = 8 consecutive steps per "
+                                      "batched launch.  real_time_factor = steps * dt / wall"}
         eng3.close()

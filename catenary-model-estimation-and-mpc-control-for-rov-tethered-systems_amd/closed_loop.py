@@ -92,8 +92,20 @@ def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_p
     stream = torch.cuda.current_stream()
     torch.cuda.synchronize()
     t_start = _time.perf_counter()
-    engine.closed_loop_device(exo.data_ptr(), n_steps, state.data_ptr(), pools.data_ptr(), n_pools, results.data_ptr(),
-                              k_offset, feedback, stream.cuda_stream, persistent=persistent, mode=mode)
+    if mode == "batched":
+        # measured rows only: no step depends on another, so n_pools consecutive steps (states = rows i .. i + n_pools - 1,
+        # candidates = the n_pools batches in order) are ONE batched launch -- the evaluation of a controller along a recorded
+        # trajectory, which is what the reference's scripts do with their data; same records as the step-by-step forms
+        if feedback or k_offset:
+            raise ValueError("mode 'batched' replays measured rows on one GPU: feedback and sharding make the steps sequential")
+        i = 0
+        while i < n_steps:
+            B = min(n_pools, n_steps - i) if i % n_pools == 0 else 1
+            engine.step_batch_device(B, exo[i].data_ptr(), pools[i % n_pools].data_ptr(), results[i].data_ptr(), stream.cuda_stream)
+            i += B
+    else:
+        engine.closed_loop_device(exo.data_ptr(), n_steps, state.data_ptr(), pools.data_ptr(), n_pools, results.data_ptr(),
+                                  k_offset, feedback, stream.cuda_stream, persistent=persistent, mode=mode)
     torch.cuda.synchronize()
     wall = _time.perf_counter() - t_start
     res = results.cpu().numpy()

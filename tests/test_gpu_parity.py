@@ -910,6 +910,17 @@ def test_persistent_closed_loop_equals_launch_per_step(rv, K, N, steps, kw, feed
     assert np.array_equal(b.cost, c.cost) and np.array_equal(b.u, c.u)
 
 
+def test_batched_replay_of_measured_rows_equals_the_step_by_step_loop(rv):
+    """Measured rows make the steps independent: n_pools of them per batched launch give the records of the per-step loop."""
+    from rovmpc.closed_loop import run_closed_loop
+    with rv.Engine(rv.MPCConfig(N=20, K=4096)) as e:
+        a = run_closed_loop(e, 12, 100, feedback=False, mode="per_step")
+        b = run_closed_loop(e, 12, 100, feedback=False, mode="batched")            # 12 launches of 8 + 4 singles
+        assert np.array_equal(a.cost, b.cost) and np.array_equal(a.u, b.u) and np.array_equal(a.theta_gamma, b.theta_gamma)
+        with pytest.raises(ValueError):
+            run_closed_loop(e, 12, 10, feedback=True, mode="batched")
+
+
 def test_persistent_closed_loop_refuses_what_it_cannot_hold(rv):
     from rovmpc.closed_loop import run_closed_loop
     with rv.Engine(rv.MPCConfig(N=20, K=8192)) as e:             # more workgroups than compute units: not wholly resident
