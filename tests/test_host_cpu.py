@@ -4,6 +4,7 @@ and the loud failure without a GPU.  No compute call into the library happens he
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -308,3 +309,36 @@ def test_euler_lagrange_derivation_matches_the_reference_route():
         rovmpc.euler_lagrange("x2**2 + x7")
     with pytest.raises(rovmpc.ExpressionError):
         rovmpc.euler_lagrange("x2**x0")
+
+
+def test_bench_quotes_a_pmc_profile_only_for_the_kernel_it_was_taken_on(tmp_path):
+    """roofline.traffic / valu_f64 come from committed rocprofv3 PMC passes; the summary carries the hash of the kernel
+    sources it was taken on, and bench.py must leave `traffic` null (and say why) when that is not the running build."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    import bench_extras
+    sha = bench.kernel_sources_sha16()
+    assert len(sha) == 16 and sha == bench.kernel_sources_sha16()
+    pmc = {"_meta": {"commit": "abc1234", "kernel_sources_sha16": sha},
+           "FETCH_SIZE": {"mean": 1300.0}, "WRITE_SIZE": {"mean": 230.0}, "SQ_INSTS_VALU": {"mean": 2.8e6},
+           "SQ_INSTS_VALU_FMA_F64": {"mean": 9e5}, "SQ_INSTS_VALU_ADD_F64": {"mean": 3e5}, "SQ_INSTS_VALU_MUL_F64": {"mean": 2e5},
+           "SQ_INSTS_VALU_TRANS_F64": {"mean": 5e4}, "SQ_WAVE_CYCLES": {"mean": 1e7}, "SQ_WAIT_ANY": {"mean": 6e6},
+           "SQ_ACTIVE_INST_VALU": {"mean": 2e6}}
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps(pmc))
+    roof = {"traffic": None}
+    bench_extras.attach_pmc(roof, str(f), sha, 19e-6, 78.6)
+    assert roof["traffic"] == (2 * 1300.0 + 230.0) * 1024 and "abc1234" in roof["traffic_source"]
+    v = roof["valu_f64"]
+    assert v["peak_tflops"] == 78.6 and abs(v["achieved_tflops"] - 64 * (2 * 9e5 + 3e5 + 2e5 + 5e4) / 19e-6 / 1e12) < 1e-9
+    assert 0 < v["frac"] < 1 and 0 < v["issue_busy_frac"] < 1 and abs(roof["wave_cycles_waiting_frac"] - 0.6) < 1e-12
+    stale = {"traffic": None}
+    bench_extras.attach_pmc(stale, str(f), "0" * 16, 19e-6, 78.6)
+    assert stale["traffic"] is None and "valu_f64" not in stale and "this build is" in stale["traffic_source"]
+    missing = {"traffic": None}
+    bench_extras.attach_pmc(missing, str(tmp_path / "nope.json"), sha, 19e-6, 78.6)
+    assert missing["traffic"] is None and "not present" in missing["traffic_source"]
+    # the committed round profile belongs to SOME build of these sources: it must at least be stamped
+    meta = json.load(open(os.path.join(ROOT, "profiles", f"{bench.PROFILE_TAG}_pmc_summary.json")))["_meta"]
+    assert len(meta["kernel_sources_sha16"]) == 16 and meta["commit"]
