@@ -258,6 +258,10 @@ def main():
             raise SystemExit(3)
         return protocol_rank(args, world, rank)
 
+    if world > 1 or args.force_collective:
+        # the sharded step keeps up to five streams busy (rollouts, three collective streams, torch's own): let the runtime
+        # open a hardware queue for each instead of folding them onto its default four (read at HIP start-up, so before torch)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import rovmpc
     from rovmpc.sharded import ShardedMPC
@@ -320,6 +324,41 @@ def main():
                 fallback_reason = f"native RCCL set-up failed: {exc}"
                 if rank == 0:
                     print(f"[bench] {fallback_reason}; using torch.distributed", file=sys.stderr)
+                smpc = None
+        if smpc is not None and (world > 1 or os.environ.get("ROVMPC_BENCH_TEST_VALIDATE")):
+            # The library's own RCCL path cannot run at world > 1 on the one-GPU build box, so every multi-rank run checks it
+            # before timing it: a few steps through it, then the same step through torch.distributed's collective -- same
+            # kernels, same slot image -- and the two global records must be the same bits on every rank, with no
+            # hand-off time-out.  All ranks agree on the outcome (one all-reduce of a flag); on a failure all of them
+            # switch to the torch.distributed collective and the line says why.
+            why = None
+            try:
+                for i in range(8):
+                    got = smpc.step_device(d_state, pools[i % args.pools])
+                smpc.synchronize()
+                got = got.cpu().numpy()
+            except Exception as exc:                      # noqa: BLE001 -- recorded in the JSON line
+                why, got = f"native RCCL path failed its check: {exc}", None
+            ref = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective)
+            want = ref.step_device(d_state, pools[7 % args.pools])
+            ref.synchronize()
+            want = want.cpu().numpy()
+            del ref
+            if os.environ.get("ROVMPC_BENCH_TEST_VALIDATE") == "fail":      # test hook: the check fails on this rank
+                got = None if got is None else got + 1.0
+            if why is None and (got is None or got.tobytes() != want.tobytes()):
+                why = "native RCCL path failed its check: global record differs from the torch.distributed collective's"
+            flag = torch.tensor([1 if why else 0], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                fallback_reason = why or "native RCCL path failed its check on another rank"
+                if rank == 0:
+                    print(f"[bench] {fallback_reason}; using torch.distributed", file=sys.stderr)
+                try:
+                    smpc.close()
+                except Exception:                         # noqa: BLE001 -- the communicator is being abandoned anyway
+                    pass
                 smpc = None
         if smpc is None:
             smpc = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective,
@@ -421,6 +460,9 @@ def main():
                        "steps_in_flight": S if smpc is None else "rollout(i+1) overlaps all-reduce(i)",
                        "collective": collective, "collective_fallback_reason": fallback_reason,
                        "backend": args.backend if dist is not None else None,
+                       "native_path_checked": bool(world > 1 and collective and collective.startswith("ncclAllReduce")),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "comm_placement": (eng.comm_placement() or None) if (collective or "").startswith("ncclAllReduce") else None,
                        "devices": devs, "candidates_per_workgroup": eng.cfg.candidates_per_block or "auto"},
             "best": {"cost": float(last[0]), "index": int(last[1])},
             "ranks_agree": ranks_agree,

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "rovmpc_step_device_allreduce": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "rovmpc_comm_join": (C.c_int, [_P, _P]),
     "rovmpc_comm_sync": (C.c_int, [_P, _P]),
+    "rovmpc_comm_placement": (C.c_char_p, [_P]),
     "rovmpc_step_batch_device": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "rovmpc_batch_costs_device": (C.c_int, [_P, C.POINTER(_P)]),
     "rovmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),

@@ -101,6 +101,8 @@ struct rovmpc_handle {
     ncclComm_t comms[NCOMM_MAX] = {};
     hipStream_t comm_streams[NCOMM_MAX] = {};
     int ncomm = 0;
+    bool comm_placed = false;             // place_comm_streams has run (first rovmpc_step_device_allreduce)
+    std::string comm_placement;           // what it found (rovmpc_get_info "comm_placement")
     // GPU-side hand-off between the caller's stream and the collective streams (no events on the caller's stream:
     // an event record costs ~3 us and a cross-stream wait ~6 us of its timeline per step, measured):
     // rolled[p] = uses of slot p whose rollout has published its row; consumed[p] = uses whose select has read it.
@@ -1599,7 +1601,9 @@ static void comm_worker(rovmpc_handle *h) {
         hipStream_t cs = h->comm_streams[job.c];
         unsigned long long *f_rolled = h->d_flags + p, *f_consumed = h->d_flags + rovmpc_handle::NSLOT + p,
                            *f_bad = h->d_flags + 2 * rovmpc_handle::NSLOT + p;
-        const unsigned long long ticks = (unsigned long long)(h->handoff_timeout_ms * 1e5);
+        // twice the rollout's own limit: a rollout that gives up waiting for its slot row (after handoff_timeout_ms) still
+        // publishes, marked bad, and the collective side must see THAT rather than race it to the same deadline
+        const unsigned long long ticks = (unsigned long long)(2.0 * h->handoff_timeout_ms * 1e5);
         std::string err;
         // the rollout of this use publishes its row with a sequence number; no event on the caller's stream
         hipLaunchKernelGGL(wait_rolled_kernel, dim3(1), dim3(64), 0, cs, (const unsigned long long *)f_rolled, job.use, h->d_err, f_bad, ticks);
@@ -1644,11 +1648,21 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     NCCLCHK(h, g_rccl.CommInitRank(&h->comm, world, id, rank));
     h->comm_rank = rank; h->comm_world = world; h->comm_flip = 0; h->comm_rr = 0;
     h->comms[0] = h->comm; h->ncomm = 1;
-    // high-priority streams: the collective and the select are short and latency-critical, and a
-    // priority stream gets a hardware queue of its own, so they really run beside the rollout
-    // kernels of the caller's stream (two same-priority streams can share a queue)
+    // The collective streams have the caller's (normal) priority.  Round 1 made them high-priority so that each got a
+    // hardware queue of its own; measured in round 2 (world 1, all-reduce kept, `bench.py --force-collective`): with the
+    // process's other high-priority stream that is four high-priority queues, and the rollout kernels on the caller's
+    // normal-priority queue then last 55 us instead of 20 (57 us per step; one or two such streams: 22 us) -- a queue
+    // of lower priority is starved while higher-priority queues hold unfinished dispatches (the waiting kernels).  At
+    // equal priority nothing starves: 21.8 us per step with three communicators when the runtime may open eight hardware
+    // queues (GPU_MAX_HW_QUEUES=8, which bench.py sets for its ranks), 25 us when they share the default four.  Sharing a
+    // queue is safe: wait(i) is always submitted after rollout(i), select(i - NSLOT) before rollout(i).
+    // ROVMPC_COMM_PRIO=hi brings the round-1 behaviour back.
     int lo = 0, hi = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    {
+        const char *e = getenv("ROVMPC_COMM_PRIO");
+        if (!(e && !strcmp(e, "hi"))) hi = 0;
+    }
     HIPCHK(h, hipStreamCreateWithPriority(&h->comm_streams[0], hipStreamNonBlocking, hi));
     HIPCHK(h, hipMalloc((void **)&h->d_flags, 3 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(h->d_flags, 0, 3 * rovmpc_handle::NSLOT * sizeof(unsigned long long)));
@@ -1708,12 +1722,110 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     return ROVMPC_OK;
 }
 
+// Where the collective streams live.  A hardware queue whose head packet waits (the wait kernel, an RCCL kernel waiting for
+// its peers) delays the completion of every kernel on the other queue of its command-processor pipe by tens of
+// microseconds -- measured: rollouts of 55 us instead of 20 when the caller's queue and a collective queue are such a pair,
+// which depends on nothing but the order in which the process happened to create its streams (queue ids k and k + 4 share a
+// pipe; tools/ubench/queue_collision.hip).  So the streams are CHOSEN: at the first sharded step, when the caller's stream is
+// known, candidate streams of normal and of high priority are probed against it (a parked lane on the candidate, a few
+// short grids on the caller's stream; a colliding or queue-sharing candidate shows up as a multiple of the undisturbed
+// time), then against the ones already chosen, until there is one per communicator.  Unused candidates are destroyed.
+// Each wait is bounded (2 ms), the whole probe takes a few milliseconds, once.  ROVMPC_COMM_PLACE=0 keeps the streams of
+// rovmpc_comm_init.
+static int place_comm_streams(rovmpc_handle *h, hipStream_t caller) {
+    h->comm_placed = true;
+    if (const char *e = getenv("ROVMPC_COMM_PLACE")) if (!strcmp(e, "0")) { h->comm_placement = "off (ROVMPC_COMM_PLACE=0)"; return ROVMPC_OK; }
+    unsigned long long *d_flag = nullptr; double *d_x = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_flag, 8));
+    HIPCHK(h, hipMemset(d_flag, 0, 8));
+    HIPCHK(h, hipMalloc((void **)&d_x, 256 * 64 * sizeof(double)));
+    HIPCHK(h, hipMemset(d_x, 0, 256 * 64 * sizeof(double)));
+    unsigned long long seq = 0;
+    const int M = 6;
+    // time of M short grids + the releasing kernel on `on` while a lane is parked on `parked` (nullptr: nobody parked)
+    auto probe = [&](hipStream_t on, hipStream_t parked, bool have_parked) -> double {
+        double best = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {
+            ++seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (have_parked) hipLaunchKernelGGL(probe_park_kernel, dim3(1), dim3(64), 0, parked, (const unsigned long long *)d_flag, seq, 200000ULL);
+            for (int m = 0; m < M; ++m) hipLaunchKernelGGL(probe_short_kernel, dim3(256), dim3(64), 0, on, d_x);
+            hipLaunchKernelGGL(probe_raise_kernel, dim3(1), dim3(64), 0, on, d_flag, seq);
+            (void)hipStreamSynchronize(on);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (have_parked) (void)hipStreamSynchronize(parked);
+            if (us < best) best = us;
+        }
+        return best;
+    };
+    (void)probe(caller, nullptr, false);                       // warm: code objects loaded, queues bound
+    const double base = probe(caller, nullptr, false);
+    const double limit = 1.5 * base + 15.0;                    // a colliding pair costs >= 20 us per kernel, M + 1 kernels
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    std::vector<hipStream_t> cand;
+    std::vector<bool> mine;                                    // created here (destroy if unused)
+    for (int c = 0; c < h->ncomm; ++c)
+        if (h->comm_streams[c]) { cand.push_back(h->comm_streams[c]); mine.push_back(true); }
+    for (int j = 0; j < 12; ++j) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, j < 6 ? 0 : hi) != hipSuccess) continue;
+        hipLaunchKernelGGL(probe_short_kernel, dim3(1), dim3(64), 0, st, d_x);      // bind it to its queue
+        (void)hipStreamSynchronize(st);
+        cand.push_back(st); mine.push_back(true);
+    }
+    std::vector<int> chosen;
+    char line[160];
+    std::string log;
+    snprintf(line, sizeof(line), "undisturbed %.0f us, limit %.0f us;", base, limit);
+    log = line;
+    for (size_t j = 0; j < cand.size() && (int)chosen.size() < h->ncomm; ++j) {
+        double worst = probe(caller, cand[j], true);                               // the candidate parks, the caller's stream works
+        if (worst <= limit) {
+            const double back = probe(cand[j], caller, true);                      // and the other way round (the rollout's own wait)
+            if (back > worst) worst = back;
+        }
+        for (size_t q = 0; q < chosen.size() && worst <= limit; ++q) {
+            double t = probe(cand[chosen[q]], cand[j], true);
+            if (t > worst) worst = t;
+            if (worst <= limit) { t = probe(cand[j], cand[chosen[q]], true); if (t > worst) worst = t; }
+        }
+        snprintf(line, sizeof(line), " %zu:%s%.0f%s", j, j < (size_t)h->ncomm ? "init " : (j < (size_t)h->ncomm + 6 ? "" : "hi "), worst, worst <= limit ? "*" : "");
+        log += line;
+        if (worst <= limit) chosen.push_back((int)j);
+    }
+    if (!chosen.empty()) {
+        std::vector<bool> used(cand.size(), false);
+        for (int c = 0; c < h->ncomm; ++c) {
+            const int j = chosen[(size_t)c % chosen.size()];
+            h->comm_streams[c] = cand[j];
+            used[j] = true;
+        }
+        for (size_t j = 0; j < cand.size(); ++j)
+            if (!used[j] && mine[j]) (void)hipStreamDestroy(cand[j]);
+        snprintf(line, sizeof(line), " -> %zu stream(s) for %d communicator(s)", chosen.size(), h->ncomm);
+    } else {
+        // nothing passed: keep what rovmpc_comm_init made
+        for (size_t j = (size_t)h->ncomm; j < cand.size(); ++j) (void)hipStreamDestroy(cand[j]);
+        snprintf(line, sizeof(line), " -> no candidate passed, streams of rovmpc_comm_init kept");
+    }
+    log += line;
+    h->comm_placement = log;
+    if (getenv("ROVMPC_COMM_PLACE_VERBOSE")) fprintf(stderr, "[rovmpc] collective stream placement: %s\n", log.c_str());
+    (void)hipFree(d_flag); (void)hipFree(d_x);
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const void *d_U, int64_t k_offset,
                                             double *d_result, void *stream) {
     if (!h) return ROVMPC_ERR_INVALID;
     if (!h->comm) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device_allreduce: call rovmpc_comm_init first");
     if (!d_state || !d_U || !d_result) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_step_device_allreduce: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    if (!h->comm_placed) {
+        int rc = place_comm_streams(h, s);
+        if (rc) return rc;
+    }
     const int p = h->comm_flip;
     h->comm_flip = (h->comm_flip + 1) % rovmpc_handle::NSLOT;
     // Slot buffer p is free once the select of NSLOT steps ago has read it.  On the host: that job has been handed
@@ -1774,6 +1886,8 @@ extern "C" int rovmpc_comm_sync(rovmpc_handle *h, void *stream) {
     return take_device_errors(h);
 }
 
+extern "C" const char *rovmpc_comm_placement(const rovmpc_handle *h) { return h ? h->comm_placement.c_str() : ""; }
+
 extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
     if (!h) return ROVMPC_ERR_INVALID;
     if (!h->comm) return ROVMPC_OK;
@@ -1795,8 +1909,14 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
         if (h->ev_selected[i]) (void)hipEventDestroy(h->ev_selected[i]);
         h->d_slots[i] = nullptr; h->ev_selected[i] = nullptr;
     }
-    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
-        if (h->comm_streams[c]) { (void)hipStreamDestroy(h->comm_streams[c]); h->comm_streams[c] = nullptr; }
+    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c) {
+        if (!h->comm_streams[c]) continue;
+        hipStream_t st = h->comm_streams[c];
+        for (int d = c; d < rovmpc_handle::NCOMM_MAX; ++d)          // communicators may share a stream after the placement
+            if (h->comm_streams[d] == st) h->comm_streams[d] = nullptr;
+        (void)hipStreamDestroy(st);
+    }
+    h->comm_placed = false;
     return take_device_errors(h);       // anything raised since the last rovmpc_comm_sync
 }
 

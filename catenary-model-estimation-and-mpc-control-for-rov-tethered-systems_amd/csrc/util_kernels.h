@@ -470,4 +470,29 @@ kabsch_kernel(const double *__restrict__ P, const double *__restrict__ Q, const 
     if (R_out) for (int a = 0; a < 9; ++a) R_out[9 * t + a] = ok ? R[a] : nan;
 }
 
+// ---- placement probe of the collective streams (rovmpc.hip::place_comm_streams) ------------------------------------------
+// A kernel that waits on one hardware queue can hold back the COMPLETION of kernels on another queue of the same
+// command-processor pipe (queues k and k + 4 share one; tools/ubench/queue_collision.hip: +24 us per kernel).  The probe
+// reproduces that on purpose: one lane parks on the candidate stream until `raise` (last on the caller's stream) lets it go
+// or 2 ms pass; meanwhile a few short grids run back to back on the caller's stream.
+__global__ void __launch_bounds__(64)
+probe_park_kernel(const unsigned long long *flag, unsigned long long want, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long give_up = wall_clock64() + ticks;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (wall_clock64() > give_up) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+__global__ void __launch_bounds__(64)
+probe_short_kernel(double *x) {
+    double v = x[blockIdx.x * 64 + threadIdx.x];
+#pragma unroll 1
+    for (int i = 0; i < 256; ++i) v = __builtin_fma(v, 1.0000001, 1e-9);
+    x[blockIdx.x * 64 + threadIdx.x] = v;
+}
+__global__ void probe_raise_kernel(unsigned long long *flag, unsigned long long v) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace rovmpc

@@ -286,6 +286,11 @@ class Engine:
         """Join + synchronise ``stream``; raises ``RovmpcError`` if a GPU-side hand-off of any enqueued step gave up."""
         self._check(self.lib.rovmpc_comm_sync(self._h, stream))
 
+    def comm_placement(self) -> str:
+        """One-line report of the collective-stream placement probe (empty before the first sharded step)."""
+        v = self.lib.rovmpc_comm_placement(self._h)
+        return v.decode() if v else ""
+
     def set_option(self, name: str, value: float):
         self._check(self.lib.rovmpc_set_option(self._h, name.encode(), float(value)))
 

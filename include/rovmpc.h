@@ -255,6 +255,12 @@ int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const 
 int rovmpc_comm_join(rovmpc_handle *h, void *stream);
 int rovmpc_comm_sync(rovmpc_handle *h, void *stream);
 int rovmpc_comm_destroy(rovmpc_handle *h);
+/* Where the collective streams went.  At the first rovmpc_step_device_allreduce the library probes candidate streams
+ * (normal and high priority) against `stream` and against each other and keeps, per communicator, one on which a waiting
+ * kernel does not delay kernel completion on the others (two hardware queues on one command-processor pipe do that to
+ * each other: rollouts of 55 us instead of 20, measured).  Returns a one-line report of the probe ("" before it ran);
+ * environment ROVMPC_COMM_PLACE=0 switches the probe off. */
+const char *rovmpc_comm_placement(const rovmpc_handle *h);
 
 /* Closed loop, device resident (BASELINE config 5): for i = 0..T-1 enqueue, without any host
  * synchronisation, (1) the plant update -- state = exo[i] (16 doubles per step in rovmpc_state

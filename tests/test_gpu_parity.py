@@ -957,6 +957,29 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(rv):
     assert d["best"]["index"] == want.index and d["best"]["cost"] == want.cost
 
 
+def test_bench_checks_the_native_collective_path_and_records_a_fallback(rv):
+    """A multi-rank bench run checks the library's own RCCL path against torch.distributed's collective before timing it and
+    falls back -- on every rank, with the reason in the line -- when the check fails.  Rehearsed on a one-rank communicator
+    with the all-reduce kept: the check passes (native path stays), and with the failure hook it switches and says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = {}
+    for hook in ("1", "fail"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--steps", "20", "--warmup", "5",
+                            "--K", "1024", "--no-kernel-timing", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, env={**base, "ROVMPC_BENCH_TEST_VALIDATE": hook, "MASTER_PORT": "29547"})
+        assert p.returncode == 0, p.stderr[-3000:]
+        out[hook] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    ok, bad = out["1"], out["fail"]
+    assert ok["config"]["collective"].startswith("ncclAllReduce") and ok["config"]["collective_fallback_reason"] is None
+    assert bad["config"]["collective"].startswith("torch.distributed") and "failed its check" in bad["config"]["collective_fallback_reason"]
+    assert ok["best"] == bad["best"]          # either path ends on the same global record
+    assert ok["config"]["hw_queues"] == "8"
+
+
 def test_handoff_timeouts_are_errors_not_wrong_records(rv):
     """The sharded step's GPU-side waits (collective <- rollout row, rollout <- select that frees the slot row) give up
     after handoff_timeout_ms.  A give-up must surface as an error of the synchronising call and a NaN cost in the affected
