@@ -35,6 +35,8 @@ struct rovmpc_handle {
     hipFunction_t jit_fn_loop = nullptr;   //            its persistent closed-loop entry
     hipFunction_t jit_fn_step = nullptr;   //            its pipelined closed-loop step entry
     hipStream_t pipe_streams[2] = {nullptr, nullptr};     // pipelined closed loop: launches alternate between the two
+    bool pipe_placed = false, pipe_stream_owned = false;  // [1] probed against the caller's stream; replaced by one of the handle's own
+    std::string pipe_placement;
     hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};
     // closed loop with GPU-side hand-off (persistent / pipelined): sequence words [2] + state ring [4][4] in one block,
     // and the granule / trajectory hand-off buffers by step parity
@@ -403,6 +405,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
                     h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj, h->d_best, h->d_blk_u};
     for (auto &ev : h->pipe_ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->pipe_stream_owned && h->pipe_streams[1]) (void)hipStreamDestroy(h->pipe_streams[1]);
     if (h->h_record) (void)hipHostFree(h->h_record);
     if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->h_err) (void)hipHostFree(h->h_err);
@@ -1722,19 +1725,18 @@ extern "C" int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t ran
     return ROVMPC_OK;
 }
 
-// Where the collective streams live.  A hardware queue whose head packet waits (the wait kernel, an RCCL kernel waiting for
-// its peers) delays the completion of every kernel on the other queue of its command-processor pipe by tens of
-// microseconds -- measured: rollouts of 55 us instead of 20 when the caller's queue and a collective queue are such a pair,
-// which depends on nothing but the order in which the process happened to create its streams (queue ids k and k + 4 share a
-// pipe; tools/ubench/queue_collision.hip).  So the streams are CHOSEN: at the first sharded step, when the caller's stream is
-// known, candidate streams of normal and of high priority are probed against it (a parked lane on the candidate, a few
-// short grids on the caller's stream; a colliding or queue-sharing candidate shows up as a multiple of the undisturbed
-// time), then against the ones already chosen, until there is one per communicator.  Unused candidates are destroyed.
-// Each wait is bounded (2 ms), the whole probe takes a few milliseconds, once.  ROVMPC_COMM_PLACE=0 keeps the streams of
-// rovmpc_comm_init.
-static int place_comm_streams(rovmpc_handle *h, hipStream_t caller) {
-    h->comm_placed = true;
-    if (const char *e = getenv("ROVMPC_COMM_PLACE")) if (!strcmp(e, "0")) { h->comm_placement = "off (ROVMPC_COMM_PLACE=0)"; return ROVMPC_OK; }
+// Where the side streams live.  A hardware queue whose head packet waits (the wait kernel, an RCCL kernel waiting for its
+// peers, a closed-loop step waiting for its predecessor's hand-off) delays the completion of every kernel on the other
+// queue of its command-processor pipe by tens of microseconds -- measured: rollouts of 55 us instead of 20 when the
+// caller's queue and a collective queue are such a pair, which depends on nothing but the order in which the process
+// happened to create its streams (queue ids k and k + 4 share a pipe; tools/ubench/queue_collision.hip).  So side streams
+// are CHOSEN: when the caller's stream is known, candidates of normal and of high priority (the `seed` streams first) are
+// probed against it -- a parked lane on one, a few short grids on the other, both ways; a colliding or queue-sharing
+// candidate shows up as a multiple of the undisturbed time -- and against the ones already chosen, until `want` are found.
+// Candidates created here and not chosen are destroyed.  Every wait is bounded (2 ms); the probe takes a few milliseconds.
+// Returns the chosen streams (possibly fewer than `want`, possibly none) and a one-line report.
+static int choose_side_streams(rovmpc_handle *h, hipStream_t caller, const std::vector<hipStream_t> &seed, int want,
+                               std::vector<hipStream_t> &chosen, std::string &log) {
     unsigned long long *d_flag = nullptr; double *d_x = nullptr;
     HIPCHK(h, hipMalloc((void **)&d_flag, 8));
     HIPCHK(h, hipMemset(d_flag, 0, 8));
@@ -1742,7 +1744,7 @@ static int place_comm_streams(rovmpc_handle *h, hipStream_t caller) {
     HIPCHK(h, hipMemset(d_x, 0, 256 * 64 * sizeof(double)));
     unsigned long long seq = 0;
     const int M = 6;
-    // time of M short grids + the releasing kernel on `on` while a lane is parked on `parked` (nullptr: nobody parked)
+    // time of M short grids + the releasing kernel on `on` while a lane is parked on `parked`
     auto probe = [&](hipStream_t on, hipStream_t parked, bool have_parked) -> double {
         double best = 1e30;
         for (int rep = 0; rep < 3; ++rep) {
@@ -1763,56 +1765,67 @@ static int place_comm_streams(rovmpc_handle *h, hipStream_t caller) {
     const double limit = 1.5 * base + 15.0;                    // a colliding pair costs >= 20 us per kernel, M + 1 kernels
     int lo = 0, hi = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    std::vector<hipStream_t> cand;
-    std::vector<bool> mine;                                    // created here (destroy if unused)
-    for (int c = 0; c < h->ncomm; ++c)
-        if (h->comm_streams[c]) { cand.push_back(h->comm_streams[c]); mine.push_back(true); }
+    std::vector<hipStream_t> cand(seed);
     for (int j = 0; j < 12; ++j) {
         hipStream_t st = nullptr;
         if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, j < 6 ? 0 : hi) != hipSuccess) continue;
         hipLaunchKernelGGL(probe_short_kernel, dim3(1), dim3(64), 0, st, d_x);      // bind it to its queue
         (void)hipStreamSynchronize(st);
-        cand.push_back(st); mine.push_back(true);
+        cand.push_back(st);
     }
-    std::vector<int> chosen;
+    std::vector<size_t> pick;
     char line[160];
-    std::string log;
     snprintf(line, sizeof(line), "undisturbed %.0f us, limit %.0f us;", base, limit);
     log = line;
-    for (size_t j = 0; j < cand.size() && (int)chosen.size() < h->ncomm; ++j) {
+    for (size_t j = 0; j < cand.size() && (int)pick.size() < want; ++j) {
         double worst = probe(caller, cand[j], true);                               // the candidate parks, the caller's stream works
         if (worst <= limit) {
-            const double back = probe(cand[j], caller, true);                      // and the other way round (the rollout's own wait)
+            const double back = probe(cand[j], caller, true);                      // and the other way round
             if (back > worst) worst = back;
         }
-        for (size_t q = 0; q < chosen.size() && worst <= limit; ++q) {
-            double t = probe(cand[chosen[q]], cand[j], true);
+        for (size_t q = 0; q < pick.size() && worst <= limit; ++q) {
+            double t = probe(cand[pick[q]], cand[j], true);
             if (t > worst) worst = t;
-            if (worst <= limit) { t = probe(cand[j], cand[chosen[q]], true); if (t > worst) worst = t; }
+            if (worst <= limit) { t = probe(cand[j], cand[pick[q]], true); if (t > worst) worst = t; }
         }
-        snprintf(line, sizeof(line), " %zu:%s%.0f%s", j, j < (size_t)h->ncomm ? "init " : (j < (size_t)h->ncomm + 6 ? "" : "hi "), worst, worst <= limit ? "*" : "");
+        snprintf(line, sizeof(line), " %zu:%s%.0f%s", j, j < seed.size() ? "seed " : (j < seed.size() + 6 ? "" : "hi "), worst, worst <= limit ? "*" : "");
         log += line;
-        if (worst <= limit) chosen.push_back((int)j);
+        if (worst <= limit) pick.push_back(j);
     }
+    std::vector<bool> used(cand.size(), false);
+    chosen.clear();
+    for (size_t q : pick) { chosen.push_back(cand[q]); used[q] = true; }
+    for (size_t j = seed.size(); j < cand.size(); ++j)
+        if (!used[j]) (void)hipStreamDestroy(cand[j]);
+    (void)hipFree(d_flag); (void)hipFree(d_x);
+    return ROVMPC_OK;
+}
+
+// The collective streams: one per communicator where the probe finds that many, else the communicators share what it found;
+// nothing found (or ROVMPC_COMM_PLACE=0): the streams of rovmpc_comm_init stay.
+static int place_comm_streams(rovmpc_handle *h, hipStream_t caller) {
+    h->comm_placed = true;
+    if (const char *e = getenv("ROVMPC_COMM_PLACE")) if (!strcmp(e, "0")) { h->comm_placement = "off (ROVMPC_COMM_PLACE=0)"; return ROVMPC_OK; }
+    std::vector<hipStream_t> seed, chosen;
+    for (int c = 0; c < h->ncomm; ++c)
+        if (h->comm_streams[c]) seed.push_back(h->comm_streams[c]);
+    std::string log;
+    int rc = choose_side_streams(h, caller, seed, h->ncomm, chosen, log);
+    if (rc) return rc;
+    char line[96];
     if (!chosen.empty()) {
-        std::vector<bool> used(cand.size(), false);
-        for (int c = 0; c < h->ncomm; ++c) {
-            const int j = chosen[(size_t)c % chosen.size()];
-            h->comm_streams[c] = cand[j];
-            used[j] = true;
+        for (hipStream_t st : seed) {
+            bool kept = false;
+            for (hipStream_t c : chosen) kept = kept || c == st;
+            if (!kept) (void)hipStreamDestroy(st);
         }
-        for (size_t j = 0; j < cand.size(); ++j)
-            if (!used[j] && mine[j]) (void)hipStreamDestroy(cand[j]);
+        for (int c = 0; c < h->ncomm; ++c) h->comm_streams[c] = chosen[(size_t)c % chosen.size()];
         snprintf(line, sizeof(line), " -> %zu stream(s) for %d communicator(s)", chosen.size(), h->ncomm);
     } else {
-        // nothing passed: keep what rovmpc_comm_init made
-        for (size_t j = (size_t)h->ncomm; j < cand.size(); ++j) (void)hipStreamDestroy(cand[j]);
         snprintf(line, sizeof(line), " -> no candidate passed, streams of rovmpc_comm_init kept");
     }
-    log += line;
-    h->comm_placement = log;
-    if (getenv("ROVMPC_COMM_PLACE_VERBOSE")) fprintf(stderr, "[rovmpc] collective stream placement: %s\n", log.c_str());
-    (void)hipFree(d_flag); (void)hipFree(d_x);
+    h->comm_placement = log + line;
+    if (getenv("ROVMPC_COMM_PLACE_VERBOSE")) fprintf(stderr, "[rovmpc] collective stream placement: %s\n", h->comm_placement.c_str());
     return ROVMPC_OK;
 }
 
@@ -2037,6 +2050,19 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     // The launches alternate between the caller's stream and the process's high-priority stream (process_pipe_stream):
     // streams of equal priority can share a hardware queue, and then nothing overlaps.
     if (!h->pipe_streams[1]) FAIL(h, ROVMPC_ERR_HIP, "no second stream for the pipelined closed loop");
+    if (!h->pipe_placed) {
+        // ... provided that stream does not sit on the caller's command-processor pipe (31 us per step instead of 15,
+        // measured in round 2 with a stream created late): probe it, and others if it fails (choose_side_streams)
+        h->pipe_placed = true;
+        const char *e = getenv("ROVMPC_COMM_PLACE");
+        if (!(e && !strcmp(e, "0"))) {
+            std::vector<hipStream_t> chosen;
+            int rc = choose_side_streams(h, s, {h->pipe_streams[1]}, 1, chosen, h->pipe_placement);
+            if (rc) return rc;
+            if (!chosen.empty() && chosen[0] != h->pipe_streams[1]) { h->pipe_streams[1] = chosen[0]; h->pipe_stream_owned = true; }
+            if (getenv("ROVMPC_COMM_PLACE_VERBOSE")) fprintf(stderr, "[rovmpc] pipelined loop's second stream: %s\n", h->pipe_placement.c_str());
+        }
+    }
     if (!h->pipe_ev[0])
         for (auto &ev : h->pipe_ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int vt = h->cfg.vt_mode;
