@@ -241,7 +241,9 @@ int rovmpc_select_device(rovmpc_handle *h, const int64_t *d_slots, int32_t world
  * must keep at least that many d_result buffers in rotation.  `stream` receives rollout kernels
  * only: the kernel publishes its row with a sequence number that the side stream polls (no event
  * record / cross-stream wait on the caller's timeline).  Up to three communicators (environment
- * ROVMPC_COMMS, default 3) serve the slots in turn so consecutive collectives overlap each other. */
+ * ROVMPC_COMMS, default 3) serve the slots in turn so consecutive collectives overlap each other; the streams they use are
+ * chosen at the first step by a placement probe against `stream` (rovmpc_comm_placement below), so keep calling with the
+ * same stream. */
 #define ROVMPC_COMM_SLOTS 4
 int rovmpc_comm_unique_id(void *id128);
 int rovmpc_comm_init(rovmpc_handle *h, const void *id128, int32_t rank, int32_t world);
