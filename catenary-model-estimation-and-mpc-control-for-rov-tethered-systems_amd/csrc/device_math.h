@@ -181,6 +181,13 @@ template <typename T> RV_DEV V3<T> rodrigues_unit(V3<T> v, V3<T> k, T s, T c) {
     T kd = dot3(k, v) * (T(1) - c);
     return {v.x * c + kv.x * s + k.x * kd, v.y * c + kv.y * s + k.y * kd, v.z * c + kv.z * s + k.z * kd};
 }
+// The same about a horizontal unit axis (kx, ky, 0) -- the theta axis of main_fun.py:75-89 always is: the terms with
+// k.z dropped in the source, because the compiler may not drop `0 * x` itself (x could be inf or NaN) and leaves four
+// multiplications by a literal zero on the dependent chain.  Same value for finite operands.
+template <typename T> RV_DEV V3<T> rodrigues_flat(V3<T> v, T kx, T ky, T s, T c) {
+    const T kd = (kx * v.x + ky * v.y) * (T(1) - c);
+    return {v.x * c + (ky * v.z) * s + kx * kd, v.y * c - (kx * v.z) * s + ky * kd, v.z * c + (kx * v.y - ky * v.x) * s};
+}
 
 // Rotation axes of transform_catenary for connection vector rel (main_fun.py:75-89, 102-103):
 // theta axis = normalize(xy_projection(rel)) x z (fallbacks [1,0,0] / [0,1,0] below 1e-9),
@@ -355,10 +362,10 @@ RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T theta, T g
     trig.sincos(theta, &st, &ct);
     trig.sincos(gamma, &sg, &cg);
     AugShape<T> a;
-    a.Bp = rodrigues_unit(rel, kt, st, ct);                          // main_fun.py:92
+    a.Bp = rodrigues_flat(rel, kt.x, kt.y, st, ct);                  // main_fun.py:92 (kt.z == 0 by construction, :75-89)
     const T omc = T(1) - cg;
     const V3<T> r3 = {-kg.y * sg + omc * kg.z * kg.x, kg.x * sg + omc * kg.z * kg.y, cg + omc * kg.z * kg.z};
-    a.m = rodrigues_unit(r3, kt, st, ct);
+    a.m = rodrigues_flat(r3, kt.x, kt.y, st, ct);
     a.lp = m_sqrt(a.Bp.x * a.Bp.x + a.Bp.y * a.Bp.y);
     a.dHp = up * a.Bp.z;
     return a;

@@ -1067,7 +1067,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     m_sincos(th, &st, &ct); m_sincos(ga, &sg, &cg);
                     const T *u = &sU[c * US + n * 3];
                     V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     store_vslots(n + 1, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
@@ -1174,7 +1174,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     m_sincos(y0, &st, &ct); m_sincos(y1, &sg, &cg);
                     const T *u = &sU[c * US + n * 3];
                     V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     T sway_n, surge_n;
                     dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, RV_PL(sA, 5, n + 1, c), RV_PL(sA, 6, n + 1, c), RV_PL(sA, 7, n + 1, c), sway_n, surge_n);
                     const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
@@ -1336,7 +1336,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
                     V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     vel_slots(B, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o.ux, o.uy, o.uz);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
@@ -1355,9 +1355,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
                         x[16] = x[13];
                         x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
-                        T s_t, c_t, s_g, c_g;
-                        sincos_near(yth, th, st, ct, s_t, c_t);
-                        sincos_near(yga, ga, sg, cg, s_g, c_g);
+                        T s_t = st, c_t = ct, s_g = sg, c_g = cg;        // first stage: the node state itself
+                        if (cfrac2 != 0) { sincos_near(yth, th, st, ct, s_t, c_t); sincos_near(yga, ga, sg, cg, s_g, c_g); }
                         x[14] = (c_t - m14) * i14; x[15] = (s_g - m15) * i15;
                         x[17] = T(0);
                     } else {
@@ -1444,7 +1443,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
                     V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
-                    v = rodrigues_unit<T>(v, kt, st, ct);
+                    v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     T sway_n, surge_n;
                     dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, o.ux, o.uy, o.uz, sway_n, surge_n);
                     const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
