@@ -1255,17 +1255,21 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30) * (T(1) - d2 * T(1.0 / 56))));
             s = s0 * cd + c0 * sd; c = c0 * cd - s0 * sd;
         };
-        auto sincos_near = [&](T x, T xanchor, T sa, T ca, T &s, T &c) {
-            const T d = x - xanchor;
-            const bool big = !(m_abs(d) < T(0.0078125));
-            T rs, rc;
+        // the pair (theta, gamma) at once: one wave vote for both
+        auto sincos_near2 = [&](T x, T xanchor, T sa, T ca, T &s, T &c, T y, T yanchor, T sb, T cb, T &s2, T &c2) {
+            const T d = x - xanchor, e = y - yanchor;
+            const bool bigx = !(m_abs(d) < T(0.0078125)), bigy = !(m_abs(e) < T(0.0078125));
+            T rs, rc, qs, qc;
             add_angle(sa, ca, d, rs, rc);
-            if (__any(big)) {                       // rare: some lane of the wave moved by more than 2^-7
+            add_angle(sb, cb, e, qs, qc);
+            if (__any(bigx | bigy)) {
                 T fs, fc;
                 m_sincos(x, &fs, &fc);
-                if (big) { rs = fs; rc = fc; }
+                if (bigx) { rs = fs; rc = fc; }
+                m_sincos(y, &fs, &fc);
+                if (bigy) { qs = fs; qc = fc; }
             }
-            s = rs; c = rc;
+            s = rs; c = rc; s2 = qs; c2 = qc;
         };
         constexpr unsigned VELMASK = 0x21f8u;       // planes 3..8 and 13: velocity, acceleration, angle_proj
         auto integrate_jit = [&]() {
@@ -1356,7 +1360,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         x[16] = x[13];
                         x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
                         T s_t = st, c_t = ct, s_g = sg, c_g = cg;        // first stage: the node state itself
-                        if (cfrac2 != 0) { sincos_near(yth, th, st, ct, s_t, c_t); sincos_near(yga, ga, sg, cg, s_g, c_g); }
+                        if (cfrac2 != 0) sincos_near2(yth, th, st, ct, s_t, c_t, yga, ga, sg, cg, s_g, c_g);
                         x[14] = (c_t - m14) * i14; x[15] = (s_g - m15) * i15;
                         x[17] = T(0);
                     } else {
@@ -1383,7 +1387,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
                 if (need_trig && n + 1 < nsteps) {
                     if (((n + 1) & 15) == 0) { m_sincos(thn, &st, &ct); m_sincos(gan, &sg, &cg); }
-                    else { sincos_near(thn, th, st, ct, st, ct); sincos_near(gan, ga, sg, cg, sg, cg); }
+                    else sincos_near2(thn, th, st, ct, st, ct, gan, ga, sg, cg, sg, cg);
                 }
                 thm = th; gam = ga; th = thn; ga = gan;
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
@@ -1487,7 +1491,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
                 if (compose_rows && n + 1 < nsteps) {
                     if (((n + 1) & 15) == 0) { m_sincos(n0, &st, &ct); m_sincos(n1, &sg, &cg); }
-                    else { sincos_near(n0, y0, st, ct, st, ct); sincos_near(n1, y1, sg, cg, sg, cg); }
+                    else sincos_near2(n0, y0, st, ct, st, ct, n1, y1, sg, cg, sg, cg);
                 }
                 y0 = n0; y1 = n1;
                 RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;

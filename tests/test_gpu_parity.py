@@ -713,10 +713,15 @@ def test_native_rccl_step_single_rank(rv):
         batches = [rv.synthetic_problem(cfg.K, cfg.N, seed=40 + i) for i in range(4)]
         want = [e.step(batches[0][0], U) for _, U in batches]      # one shared state, four candidate batches
         smpc = NativeShardedMPC(e, rank=0, world=1)
+        assert e.comm_placement() == ""                                # the collective streams are placed at the first step
         d_state = torch.tensor(batches[0][0], device=dev)
         dU = [torch.tensor(U, device=dev) for _, U in batches]
         outs = [smpc.step_device(d_state, dU[i]) for i in range(4)]    # four steps in flight (SLOTS = 4)
         smpc.synchronize()
+        # the placement probe ran against the caller's stream and found a collective stream per communicator that neither
+        # shares its hardware queue nor its command-processor pipe (a candidate that does is reported, not starred)
+        report = e.comm_placement()
+        assert report.startswith("undisturbed") and "stream(s) for" in report and "*" in report, report
         recs = [(i, outs[i].clone()) for i in range(4)]
         outs = [smpc.step_device(d_state, dU[3 - i]) for i in range(4)]  # and the buffers are reusable
         smpc.synchronize()
