@@ -864,6 +864,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const int r = (N * CK) % 256;
         if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
     }
+    // the integrating wave reports its progress only as far as somebody waits for it (the nodes of the early batch)
+    const int prog_until = early > 0 ? (early + CK - 1) / CK : 0;
     // Measured and rejected: letting the geometry waves chase the integrating wave node by node
     // (LDS progress flags) -- a phase-4b item is a ~4 us dependent chain whatever the lane count, so
     // the tail after the last integration step does not shrink and the extra waves slow the
@@ -983,7 +985,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;
                 // progress word for the early phase-4b batch: one wave's DS operations complete in order,
                 // so the relaxed store cannot pass the theta store above
-                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             auto run = [&](auto FAST) {
                 int n = 0;
@@ -1298,7 +1300,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             auto vel_slots = [&](T *x, T vx, T vy, T vz, T ax, T ay, T az, T ux, T uy, T uz) {
                 if (uses(13)) {
                     const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
-                    T ap = (vx * ux + vy * uy + vz * uz) / nv;
+                    T ap = (vx * ux + vy * uy + vz * uz) * fast_rcp(nv);      // nv >= 1e-8 (or NaN / inf, which stay that)
                     if (!gen2) ap = m_clip(ap, T(-1), T(1));
                     x[13] = (ap - sMean[apslot]) * sInv[apslot];
                 }
@@ -1392,7 +1394,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 thm = th; gam = ga; th = thn; ga = gan;
                 RV_PL(sY, 0, n + 1, c) = th; RV_PL(sY, 1, n + 1, c) = ga;
                 // progress word for the early phase-4b batch (one wave's DS operations complete in order)
-                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             int n = 0;
             for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
@@ -1495,7 +1497,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
                 y0 = n0; y1 = n1;
                 RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
-                if (tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             int n = 0;
             for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
