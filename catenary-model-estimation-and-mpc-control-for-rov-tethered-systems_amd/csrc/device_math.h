@@ -96,7 +96,48 @@ RV_DEV double fast_sin_k(double x, const SinK &K) {
     const double v = ::fma(r * z, p, r);
     return ((int)k & 1) ? -v : v;
 }
-// Trig context: fp64 carries the pinned constants, fp32 uses the device library directly.
+// fp32 (BASELINE config 3).  The device library's sinf / sincosf inline a Payne-Hanek reduction beside every call and
+// evaluate both polynomials for either result: ~40 instructions and six mask operations on the hot path, twice the fp64
+// chain's own sine.  Same construction as above in single precision: k = rint(x / pi), r = x - k pi by two FMAs (exact
+// product, |k| < 2^14 below the limit), odd polynomial to r^9 fitted on [-pi/2, pi/2] (1.9 ulp measured against fp64 over
+// 2e5 points), sign (-1)^k -- 13 instructions, no branch; the pair reduces by pi/2 and uses the fdlibm single-precision
+// kernels (k_sinf.c / k_cosf.c).  Larger arguments (and NaN) take the library, out of line.
+constexpr float TRIGF_FAST_LIMIT = 32768.0f;
+__device__ __attribute__((noinline)) float slow_sinf_f32(float x) { return ::sinf(x); }
+__device__ __attribute__((noinline)) float2 slow_sincos_f32(float x) { float s, c; ::sincosf(x, &s, &c); return make_float2(s, c); }
+template <bool CHECKED = true>
+RV_DEV float fast_sinf_k(float x) {
+    if (CHECKED && !(::fabsf(x) < TRIGF_FAST_LIMIT)) return slow_sinf_f32(x);
+    const float k = ::rintf(x * 0.318309886f);
+    float r = ::fmaf(-k, 3.14159274f, x);
+    r = ::fmaf(-k, -8.74227766e-8f, r);
+    const float z = r * r;
+    float p = ::fmaf(z, 2.6324394e-06f, -0.00019822021f);
+    p = ::fmaf(z, p, 0.008333237f);
+    p = ::fmaf(z, p, -0.16666666f);
+    const float v = ::fmaf(r * z, p, r);
+    return ((int)k & 1) ? -v : v;
+}
+RV_DEV void fast_sincosf_k(float x, float *s, float *c) {
+    if (!(::fabsf(x) < TRIGF_FAST_LIMIT)) { const float2 r = slow_sincos_f32(x); *s = r.x; *c = r.y; return; }
+    const float k = ::rintf(x * 0.636619772f);
+    float r = ::fmaf(-k, 1.57079637f, x);
+    r = ::fmaf(-k, -4.37113883e-8f, r);
+    const float z = r * r;
+    float ps = ::fmaf(z, 2.7183114e-06f, -0.00019839335f);
+    ps = ::fmaf(z, ps, 0.0083333294f);
+    ps = ::fmaf(z, ps, -0.16666667f);
+    const float sr = ::fmaf(r * z, ps, r);
+    float pc = ::fmaf(z, 2.4390449e-05f, -0.0013886764f);
+    pc = ::fmaf(z, pc, 0.041666623f);
+    const float cr = ::fmaf(z * z, pc, ::fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// Trig context: fp64 carries the pinned constants, fp32 the kernels above (constants are 32-bit literals).
 template <typename T> struct Trig;
 template <> struct Trig<double> {
     TrigK K;
@@ -110,19 +151,19 @@ template <> struct Trig<double> {
 };
 template <> struct Trig<float> {
     RV_DEV explicit Trig(bool) {}
-    RV_DEV float sin(float x) const { return ::sinf(x); }
-    RV_DEV float sin_bounded(float x) const { return ::sinf(x); }
-    static RV_DEV bool bounded(float b) { return b == b; }
-    RV_DEV void sincos(float x, float *s, float *c) const { ::sincosf(x, s, c); }
+    RV_DEV float sin(float x) const { return fast_sinf_k<true>(x); }
+    RV_DEV float sin_bounded(float x) const { return fast_sinf_k<false>(x); }
+    static RV_DEV bool bounded(float b) { return b < TRIGF_FAST_LIMIT; }
+    RV_DEV void sincos(float x, float *s, float *c) const { fast_sincosf_k(x, s, c); }
 };
 // sine alone (expressions of loaded models): the one-polynomial kernel, ~22 instructions against ~38 for the pair;
 // above TRIG_FAST_LIMIT it takes the library's reduction like the pair does
 RV_DEV double m_sin(double x) { return fast_sin_k<true>(x, sin_constants(false)); }
-RV_DEV float  m_sin(float x)  { return ::sinf(x); }
+RV_DEV float  m_sin(float x)  { return fast_sinf_k<true>(x); }
 RV_DEV double m_cos(double x) { double s, c; fast_sincos_f64(x, &s, &c); return c; }
-RV_DEV float  m_cos(float x)  { return ::cosf(x); }
+RV_DEV float  m_cos(float x)  { float s, c; fast_sincosf_k(x, &s, &c); return c; }
 RV_DEV void m_sincos(double x, double *s, double *c) { fast_sincos_f64(x, s, c); }
-RV_DEV void m_sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
+RV_DEV void m_sincos(float x, float *s, float *c) { fast_sincosf_k(x, s, c); }
 RV_DEV double m_sinh(double x) { return ::sinh(x); }
 RV_DEV float  m_sinh(float x)  { return ::sinhf(x); }
 RV_DEV double m_cosh(double x) { return ::cosh(x); }
@@ -136,7 +177,7 @@ RV_DEV float  m_exp(float x)  { return ::expf(x); }
 RV_DEV double m_log(double x) { return ::log(x); }
 RV_DEV float  m_log(float x)  { return ::logf(x); }
 RV_DEV double m_sqrt(double x) { return ::sqrt(x); }
-RV_DEV float  m_sqrt(float x)  { return ::sqrtf(x); }
+RV_DEV float  m_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32: 1 ulp, no fix-up sequence
 RV_DEV double m_pow(double x, double y) { return ::pow(x, y); }
 RV_DEV float  m_pow(float x, float y)  { return ::powf(x, y); }
 RV_DEV double m_abs(double x) { return ::fabs(x); }
@@ -155,7 +196,11 @@ RV_DEV double fast_rcp(double x) {
     r = ::fma(r, ::fma(-x, r, 1.0), r);
     return ::fma(r, ::fma(-x, r, 1.0), r);
 }
-RV_DEV float fast_rcp(float x) { return 1.0f / x; }
+RV_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32: 1 ulp
+// a / b on the geometry chains: IEEE in fp64; in fp32 (parity rule: same arg-min or |dJ|/J < 1e-4) one v_rcp_f32 and a
+// multiplication instead of the ten-instruction division sequence
+RV_DEV double m_div(double a, double b) { return a / b; }
+RV_DEV float  m_div(float a, float b)  { return a * __builtin_amdgcn_rcpf(b); }
 
 template <typename T> RV_DEV T m_eps();
 template <> RV_DEV double m_eps<double>() { return 2.220446049250313e-16; }
@@ -195,11 +240,11 @@ template <typename T> RV_DEV V3<T> rodrigues_flat(V3<T> v, T kx, T ky, T s, T c)
 template <typename T> RV_DEV void theta_gamma_axes(V3<T> rel, V3<T> &th_axis, V3<T> &ga_axis) {
     T nxy = m_sqrt(rel.x * rel.x + rel.y * rel.y);
     T ex, ey;
-    if (nxy < T(1e-9)) { ex = T(1); ey = T(0); } else { T inv = T(1) / nxy; ex = rel.x * inv; ey = rel.y * inv; }
+    if (nxy < T(1e-9)) { ex = T(1); ey = T(0); } else { T inv = m_div(T(1), nxy); ex = rel.x * inv; ey = rel.y * inv; }
     // cross([ex,ey,0],[0,0,1]) = [ey,-ex,0]; its norm is 1 (unit xy) so the second fallback
     // of main_fun.py:86-89 can only trigger for a NaN input.
     th_axis = {ey, -ex, T(0)};
-    T inv = T(1) / m_sqrt(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z);
+    T inv = m_div(T(1), m_sqrt(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z));
     ga_axis = {rel.x * inv, rel.y * inv, rel.z * inv};
 }
 
@@ -265,8 +310,8 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
     for (int s = 0; s < NS; ++s) {
         const T L2 = L * L - dH[s] * dH[s];
         const T sq = m_sqrt(L2);
-        r[s] = sq / l[s];
-        rm1[s] = (L2 - l[s] * l[s]) / (l[s] * (sq + l[s]));
+        r[s] = m_div(sq, l[s]);
+        rm1[s] = m_div(L2 - l[s] * l[s], l[s] * (sq + l[s]));
         const bool warm = u_warm && u_warm[s] > T(0) && ch_warm[s] > r[s] && rm1[s] > T(0) && m_finite(r[s]);
         if (warm) {
             u[s] = u_warm[s];
@@ -315,7 +360,7 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
         for (int it = 0; it < 40 && moving[s] && ok[s]; ++it) halley(s);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const T C = T(2) * u[s] / l[s];
+        const T C = m_div(T(2) * u[s], l[s]);
         const bool in = ok[s] && C >= c_lo && C <= c_hi;
         out[s].u = u[s]; out[s].r = r[s];
         out[s].C = in ? C : m_nan<T>();
@@ -342,7 +387,7 @@ template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) 
 // Tension rule of main_fun.py:302-305: T = (w/L) l / (2 sinh(C l / 2)), NaN -> (w/L) l / 2.
 // At the root sinh(C l / 2) = sinh(u) = r u, which the solve already holds.
 template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
-    return (c.C == c.C) ? (w_per_len * l) / (T(2) * c.r * c.u) : w_per_len * l / T(2);
+    return (c.C == c.C) ? m_div(w_per_len * l, T(2) * c.r * c.u) : w_per_len * l / T(2);
 }
 
 // Lowest z (in the "up" sense) of transform_catenary(A, A+rel, Catenary(L), theta, gamma)[3]
@@ -380,13 +425,13 @@ RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) 
     if (c.C == c.C) {
         // a valid root means L^2 - dH'^2 > l'^2 > 0: every quantity inverted below is finite and positive
         const T eu = m_exp(c.u);
-        T E = m_sqrt((L + a.dHp) / (L - a.dHp)) * fast_rcp(eu);    // e^{a}
+        T E = m_sqrt(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(eu);    // e^{a}
         T Ei = fast_rcp(E);
-        const T invden = T(1) / T(M - 1);
+        const T invden = m_div(T(1), T(M - 1));
         const T Ed = m_exp(T(2) * c.u * invden), Edi = fast_rcp(Ed);
         const T ch0 = T(0.5) * (E + Ei);                 // cosh(C' x0)
         const T hx = a.m.x * a.Bp.x + a.m.y * a.Bp.y;    // horizontal part of m . q_j is t_j * hx
-        const T mz = a.m.z * up / c.C;
+        const T mz = m_div(a.m.z * up, c.C);
         best = m_inf<T>();
         bool bad = false;                                // np.min propagates NaN
         for (int j = 0; j < M; ++j) {

@@ -727,7 +727,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T Vx, Vy, Vz, Wx, Wy, Wz;
             vel(c, n, Vx, Vy, Vz); vel(c, m, Wx, Wy, Wz);
             const T qx = Qx - P0x, qy = Qy - P0y, qz = Qz - P0z;
-            const T inq = T(1) / (m_sqrt(qx * qx + qy * qy + qz * qz) + T(1e-8));
+            const T inq = m_div(T(1), m_sqrt(qx * qx + qy * qy + qz * qz) + T(1e-8));
             T sway_n, surge_n, sway_m, surge_m;
             dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, ux, uy, uz, sway_n, surge_n);
             dd_surge_sway<T>(kk.vs * Wx, kk.vs * Wy, kk.vs * Wz, qx * inq, qy * inq, qz * inq, sway_m, surge_m);
@@ -760,7 +760,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (n == 0) { Ax = A0x; Ay = A0y; Az = A0z; }
             else { vel(c, n - 1, Wx, Wy, Wz); Ax = (Vx - Wx) * kk.inv_h; Ay = (Vy - Wy) * kk.inv_h; Az = (Vz - Wz) * kk.inv_h; }
             const T nv = m_sqrt(Vx * Vx + Vy * Vy + Vz * Vz) + T(1e-8);      // :30
-            T ap = (Vx * ux + Vy * uy + Vz * uz) / nv;
+            T ap = m_div(Vx * ux + Vy * uy + Vz * uz, nv);
             const int apslot = fmap == ROVMPC_FEATURES_GEN2 ? 16 : 13;
             if (fmap != ROVMPC_FEATURES_GEN2) ap = m_clip(ap, T(-1), T(1));              // :31 (generation 2 does not clip)
             if (uses(3)) RV_PX(3, n, c) = (Vx - sMean[3]) * sInv[3];
