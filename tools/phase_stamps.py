@@ -31,6 +31,14 @@ print("model", MODEL, "->", eng.model_path)
 state, U = rovmpc.synthetic_problem(K, N)
 for _ in range(5):
     eng.step(state, U)
+if os.environ.get("STAMPS_BACK_TO_BACK"):        # steady state: launches back to back on one stream, stamps of the last one
+    import torch
+    dev = torch.device("cuda", 0)
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    d_res = torch.empty(eng.result_len, dtype=torch.float64, device=dev)
+    for _ in range(int(os.environ["STAMPS_BACK_TO_BACK"])):
+        eng.step_device(d_state.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
 lib = eng.lib
 lib.rovmpc_diag_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
 buf = np.zeros((K, 16), dtype=np.uint64)
@@ -66,3 +74,10 @@ for c in np.unique(cu):
     e = e[np.argsort(e[:, 0], kind="stable")]
     peaks.append(np.cumsum(e[:, 1]).max())
 print(f"peak workgroups alive per CU: median {np.median(peaks):.0f}  max {max(peaks)}; workgroups per CU median {np.median(np.bincount(np.unique(cu, return_inverse=True)[1])):.0f}")
+
+# dispatch ramp: start of the workgroups by XCC (hwreg XCC_ID) and by position in the grid
+xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
+print("start by XCC (us after the first workgroup): " + "  ".join(f"xcc{x}: {np.median(start[xcc == x] - t0) / 100:.2f} [{(start[xcc == x].min() - t0) / 100:.2f}..{(start[xcc == x].max() - t0) / 100:.2f}] n={int((xcc == x).sum())}" for x in np.unique(xcc)))
+order = np.argsort(start, kind="stable")
+print("start of the k-th workgroup to start: " + "  ".join(f"{k}: {(start[order[k]] - t0) / 100:.2f}" for k in (0, 1, 2, 4, 8, 16, 32, 64, 128, 192, 255) if k < len(order)))
+print("start by blockIdx: " + "  ".join(f"{b}: {(start[b] - t0) / 100:.2f}" for b in (0, 1, 2, 7, 8, 9, 16, 64, 128, 255) if b < len(start)))
