@@ -13,7 +13,7 @@ from .model import (DynamicsModel, default_model, generation2_model, generation3
                     chosen_complexity_from_txt, FEATURE_NAMES_GEN1)
 from .engine import Engine, MPCConfig, MPCState, StepResult, default_engine, state_array
 from .geometry import (rodrigues_rotation, transform_catenary, transform_catenary_batch, solve_catenary,
-                       cable_tension, Catenary, lowest_point, rotation_axes, velocity_transform,
+                       cable_tension, Catenary, Catenary3D, compute_catenary_3D, lowest_point, rotation_axes, velocity_transform,
                        kabsch_velocity_transform, compute_rotation_kabsch)
 from .integrate import (SymbolicRegressor, rk4_integration, integrate_theta_gamma, rk4_theta_gamma,
                         integrate_second_order)

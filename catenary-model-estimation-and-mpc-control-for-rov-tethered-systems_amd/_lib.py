@@ -89,6 +89,7 @@ _SIGNATURES = {
     "rovmpc_solve_catenary": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, _P, _P]),
     "rovmpc_rodrigues": (C.c_int, [_P, _P, _P, _P, C.c_int64, _P]),
     "rovmpc_catenary_points": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, C.c_int32, _P, _P, _P]),
+    "rovmpc_compute_catenary_3d": (C.c_int, [_P, _P, _P, C.c_double, C.c_int64, C.c_int32, _P, _P]),
     "rovmpc_transform_catenary": (C.c_int, [_P, _P, _P, _P, _P, C.c_double, C.c_int64, C.c_int32, _P, _P, _P]),
     "rovmpc_velocity_transform": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "rovmpc_extract_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P]),

@@ -1340,6 +1340,26 @@ extern "C" int rovmpc_catenary_points(rovmpc_handle *h, const double *A, const d
     return ROVMPC_OK;
 }
 
+extern "C" int rovmpc_compute_catenary_3d(rovmpc_handle *h, const double *p0, const double *p1, double rope_length, int64_t n,
+                                          int32_t num_points, double *pts, double *a_out) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (n < 0 || num_points < 2 || (n > 0 && (!p0 || !p1 || !pts))) FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_compute_catenary_3d: bad argument");
+    if (n == 0) return ROVMPC_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    DevBuf dA, dB, dP, dQ;
+    UPLOAD(h, dA, p0, (size_t)n * 3 * sizeof(double));
+    UPLOAD(h, dB, p1, (size_t)n * 3 * sizeof(double));
+    HIPCHK(h, dP.alloc((size_t)n * num_points * 3 * sizeof(double)));
+    HIPCHK(h, dQ.alloc((size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(catenary_3d_kernel, dim3(grid_for(n, 128)), dim3(128), 0, h->stream, dA.as<double>(), dB.as<double>(), rope_length,
+                       (long long)n, num_points, dP.as<double>(), dQ.as<double>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(pts, dP.p, (size_t)n * num_points * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (a_out) HIPCHK(h, hipMemcpyAsync(a_out, dQ.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_transform_catenary(rovmpc_handle *h, const double *A, const double *B, const double *theta,
                                          const double *gamma, double L, int64_t n, int32_t M, double *out, int32_t *npts,
                                          double *z_low) {

@@ -470,6 +470,59 @@ kabsch_kernel(const double *__restrict__ P, const double *__restrict__ Q, const 
     if (R_out) for (int a = 0; a < 9; ++a) R_out[9 * t + a] = ok ? R[a] : nan;
 }
 
+// compute_catenary_3D(p0, p1, rope_length, num_points) (models/catenary_3d.py:5-39) -- the catenary generator the reference
+// itself holds (pympc's is absent): straight np.linspace when the rope is not longer than the distance (:13-14), otherwise
+// the fixed point a <- a L / (2 a sinh(d / 2a)) from a = d / 2, at most 100 rounds, stop when |a_new - a| < 1e-6 (:18-24),
+// and z lowered by a cosh(half_span / a) - a cosh(x / a) along the chord (:26-37).  One lane per pair, the reference's own
+// operation order (no contraction: its NumPy evaluates every product and sum separately).  a_out[i] = NaN for the straight case.
+// (The update multiplies a by L / arc(a) > 1 while the rope is longer than the arc, i.e. it walks AWAY from the hanging
+// solution and normally spends all 100 rounds: the curve it returns is nearly flat, its sag the difference of two numbers
+// of size a ~ 1e6..1e30 -- rounding noise in multiples of ulp(a).  Reproduced as it is; parity with the host's libm can
+// therefore only be asked to a few ulp of a cosh(half / a), and the tests ask exactly that.)
+__global__ void __launch_bounds__(128)
+catenary_3d_kernel(const double *P0, const double *P1, double rope, long long n, int M, double *pts, double *a_out) {
+#pragma clang fp contract(off)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x0 = P0[3 * i], y0 = P0[3 * i + 1], z0 = P0[3 * i + 2];
+    const double x1 = P1[3 * i], y1 = P1[3 * i + 1], z1 = P1[3 * i + 2];
+    const double dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
+    const double direct = ::sqrt((dx * dx + dy * dy) + dz * dz);
+    double *p = pts + (size_t)i * M * 3;
+    if (rope <= direct || !(direct == direct)) {
+        // np.linspace(p0, p1, M): start + j * step, the last sample set to the stop value (a NaN distance has no `<=`, so the
+        // reference would go on and produce NaN; so does this branch)
+        const double sx = dx / (double)(M - 1), sy = dy / (double)(M - 1), sz = dz / (double)(M - 1);
+        for (int j = 0; j < M; ++j) {
+            const bool last = j == M - 1;
+            p[3 * j] = last ? x1 : x0 + (double)j * sx;
+            p[3 * j + 1] = last ? y1 : y0 + (double)j * sy;
+            p[3 * j + 2] = last ? z1 : z0 + (double)j * sz;
+        }
+        if (a_out) a_out[i] = m_nan<double>();
+        return;
+    }
+    const double half = direct / 2.0;
+    double a = half;
+    for (int it = 0; it < 100; ++it) {
+        const double lhs = 2.0 * a * ::sinh(direct / (2.0 * a));
+        const double a_new = a * rope / lhs;
+        const bool done = ::fabs(a_new - a) < 1e-6;
+        a = a_new;
+        if (done) break;
+    }
+    const double off = a * ::cosh(half / a);
+    for (int j = 0; j < M; ++j) {
+        const double t = (double)j / (double)(M - 1);
+        const double x_pos = t * direct - half;
+        const double sag = off - a * ::cosh(x_pos / a);
+        p[3 * j] = x0 + dx * t;
+        p[3 * j + 1] = y0 + dy * t;
+        p[3 * j + 2] = (z0 + dz * t) - sag;
+    }
+    if (a_out) a_out[i] = a;
+}
+
 // ---- placement probe of the collective streams (rovmpc.hip::place_comm_streams) ------------------------------------------
 // A kernel that waits on one hardware queue can hold back the COMPLETION of kernels on another queue of the same
 // command-processor pipe (queues k and k + 4 share one; tools/ubench/queue_collision.hip: +24 us per kernel).  The probe

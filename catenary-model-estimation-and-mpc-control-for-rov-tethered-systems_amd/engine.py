@@ -397,6 +397,19 @@ class Engine:
                                                     _ptr(params)))
         return pts, valid.astype(bool), params
 
+    def compute_catenary_3d(self, p0, p1, rope_length: float, num_points: int):
+        """models/catenary_3d.py:5-39 for n pairs: (pts (n, num_points, 3), a (n,)); a = NaN where the rope is taut."""
+        A = np.ascontiguousarray(p0, np.float64).reshape(-1, 3); B = np.ascontiguousarray(p1, np.float64).reshape(-1, 3)
+        if A.shape != B.shape:
+            raise ValueError("p0 and p1 must have the same shape")
+        if num_points < 2:
+            raise ValueError("num_points must be >= 2")
+        n = A.shape[0]
+        pts = np.empty((n, num_points, 3)); a = np.empty(n)
+        self._check(self.lib.rovmpc_compute_catenary_3d(self._h, _ptr(A), _ptr(B), float(rope_length), n, int(num_points),
+                                                        _ptr(pts), _ptr(a)))
+        return pts, a
+
     def transform_catenary(self, A, B, theta, gamma, L: float, M: int):
         A = np.ascontiguousarray(A, np.float64).reshape(-1, 3); B = np.ascontiguousarray(B, np.float64).reshape(-1, 3)
         n = A.shape[0]

@@ -4,6 +4,7 @@
     transform_catenary(point_A, point_B, catenary_fn, theta, gamma)  main_fun.py:38-111
     solve_catenary(l, delta_H, L)                                    main_fun.py:418-431
     Catenary(length=3., reference_frame='ENU')(a, b)                 catenary.py:10,25-29
+    compute_catenary_3D(p0, p1, rope_length, num_points), Catenary3D models/catenary_3d.py:5-39
     lowest_point(points)                                             fully_augmented_catenary.py:21-22
     velocity_transform(R, v)                                         velocity_transform_batch.py:100-101
     compute_rotation_kabsch(P, Q), kabsch_velocity_transform(...)    velocity_transform_batch.py:8-19, 71-107
@@ -91,6 +92,36 @@ class Catenary:
     def batch(self, A, B):
         """(pts (n,M,3), valid (n,), params (n,3)) for n pairs in one launch."""
         return self._engine().catenary_points(A, B, self.length, self.n_points)
+
+
+def compute_catenary_3D(p0, p1, rope_length, num_points):
+    """models/catenary_3d.py:5-39, same name and arguments: ``(num_points, 3)`` points from ``p0`` to ``p1`` -- the hanging
+    curve found by the reference's fixed-point iteration on the catenary parameter, or the straight ``np.linspace`` when the
+    rope is not longer than the distance.  ``p0`` / ``p1`` of shape ``(n, 3)`` give ``(n, num_points, 3)`` in one launch."""
+    a = np.asarray(p0, dtype=np.float64)
+    pts, _ = default_engine().compute_catenary_3d(a, p1, rope_length, num_points)
+    return pts[0] if a.ndim == 1 else pts
+
+
+class Catenary3D:
+    """The reference's own in-repo catenary generator (``compute_catenary_3D``, models/catenary_3d.py:5-39) behind the
+    ``catenary_fn`` interface of ``transform_catenary`` (main_fun.py:63-69): ``Catenary3D(length, num_points)(a, b)`` returns a
+    4-tuple whose ``[3]`` is the ``(num_points, 3)`` curve (``[0]`` = the catenary parameter, NaN when taut).  Unlike
+    ``Catenary`` (a stand-in for the absent pympc class) every number it produces is pinned to reference code."""
+
+    def __init__(self, length: float = 3.0, num_points: int = 100):
+        if num_points < 2:
+            raise ValueError("num_points must be >= 2")
+        self.length = float(length)
+        self.num_points = int(num_points)
+
+    def __call__(self, a, b):
+        pts, par = default_engine().compute_catenary_3d(a, b, self.length, self.num_points)
+        return (float(par[0]), None, None, pts[0])
+
+    def batch(self, A, B):
+        """(pts (n, num_points, 3), a (n,)) for n pairs in one launch."""
+        return default_engine().compute_catenary_3d(A, B, self.length, self.num_points)
 
 
 def transform_catenary(point_A, point_B, catenary_fn: Callable, theta_rad, gamma_rad):

@@ -343,6 +343,14 @@ int rovmpc_rodrigues(rovmpc_handle *h, const double *v, const double *axis,
 int rovmpc_catenary_points(rovmpc_handle *h, const double *A, const double *B, double L,
                            int64_t n, int32_t M, double *pts, int32_t *valid, double *params);
 
+/* compute_catenary_3D(p0, p1, rope_length, num_points) (models/catenary_3d.py:5-39), the catenary generator the reference
+ * itself holds, for n pairs: pts[n][num_points][3] from p0 to p1 (the straight np.linspace when rope_length <= |p1 - p0|,
+ * :13-14); a_out[n] (may be NULL) = the catenary parameter the fixed point of :18-24 stopped at, NaN for the straight case.
+ * Usable as the `catenary_fn` of transform_catenary (the host layer's Catenary3D), which pins the whole augmented-catenary
+ * path to reference code. */
+int rovmpc_compute_catenary_3d(rovmpc_handle *h, const double *p0, const double *p1, double rope_length,
+                               int64_t n, int32_t num_points, double *pts, double *a_out);
+
 /* transform_catenary(point_A, point_B, Catenary(L), theta, gamma) (main_fun.py:38-111):
  * out[4][n][M][3] = original, theta_rotated, theta_aligned, final; npts[n][2] = number of
  * meaningful rows in out[0] and out[1..3] (M, or 2 for the straight-segment fallback of

@@ -308,6 +308,42 @@ class Catenary:
         return (C, sag, x0, pts)
 
 
+def compute_catenary_3d(p0, p1, rope_length, num_points):
+    """models/catenary_3d.py:5-39 (compute_catenary_3D), the catenary generator the reference itself holds: straight
+    np.linspace when the rope is not longer than the distance (:13-14); otherwise the fixed point on the catenary
+    parameter from a = half the distance, at most 100 rounds, stop at |a_new - a| < 1e-6 (:16-24); z lowered by
+    a cosh(half / a) - a cosh(x / a) along the chord (:26-37).  Pinned: tests/golden/kat_catenary_3d.npz holds the
+    outputs of the reference's own function."""
+    p0 = np.asarray(p0, float); p1 = np.asarray(p1, float)
+    d = p1 - p0
+    direct = np.sqrt(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
+    if rope_length <= direct:
+        return np.linspace(p0, p1, num_points)
+    half = direct / 2
+    a = half
+    for _ in range(100):
+        a_new = a * rope_length / (2 * a * np.sinh(direct / (2 * a)))
+        stop = abs(a_new - a) < 1e-6
+        a = a_new
+        if stop:
+            break
+    off = a * np.cosh(half / a)
+    t = np.arange(num_points) / (num_points - 1)
+    pts = p0[None, :] + d[None, :] * t[:, None]
+    pts[:, 2] -= off - a * np.cosh((t * direct - half) / a)
+    return pts
+
+
+class Catenary3D:
+    """catenary_fn built on compute_catenary_3d (what main_fun.py:63-69 expects: [3] = points)."""
+
+    def __init__(self, length=3.0, num_points=100):
+        self.length, self.num_points = float(length), int(num_points)
+
+    def __call__(self, a, b):
+        return (None, None, None, compute_catenary_3d(a, b, self.length, self.num_points))
+
+
 def transform_catenary(point_A, point_B, catenary_fn, theta_rad, gamma_rad):
     """main_fun.py:38-111, statement by statement (returns the 4-tuple the code returns)."""
     point_A = np.asarray(point_A, float); point_B = np.asarray(point_B, float)

@@ -26,6 +26,16 @@ int main(void) {
     if (!isnan(C[5]) || !isnan(C[6])) { fprintf(stderr, "expected NaN for the two no-root cases\n"); return 1; }
     if (fabs(T[5] - 1.521 / 3.0 * 0.5 / 2) > 1e-15) { fprintf(stderr, "tension fallback wrong\n"); return 1; }
 
+    /* compute_catenary_3D (models/catenary_3d.py:5-39): a taut pair is the straight np.linspace, end points exact */
+    {
+        const double p0[3] = {0, 0, 0}, p1[3] = {3.0, 1.0, 0.5};
+        double pts[4 * 3], a1;
+        CHECK(h, rovmpc_compute_catenary_3d(h, p0, p1, 3.0, 1, 4, pts, &a1));
+        if (!isnan(a1) || pts[9] != 3.0 || pts[10] != 1.0 || pts[11] != 0.5 || fabs(pts[3] - 1.0) > 1e-15) {
+            fprintf(stderr, "compute_catenary_3d: straight case wrong\n"); return 1;
+        }
+    }
+
     /* model: dtheta/dt = -0.05 * x16 - 0.05 * sin(x3), dgamma/dt = x15 - x17 (identity scaler) */
     double mean[18] = {0}, scale[18];
     for (int i = 0; i < 18; ++i) scale[i] = 1.0;

@@ -131,6 +131,45 @@ def test_transform_catenary_fused_and_generic(rv, orc, golden_dir):
     np.testing.assert_allclose(z, zref, rtol=1e-10, atol=1e-12)
 
 
+def test_compute_catenary_3d_and_the_fully_pinned_augmented_path(rv, orc, golden_dir):
+    """compute_catenary_3D (models/catenary_3d.py:5-39) on the GPU against the outputs of the reference's own function, one
+    pair at a time and batched; then transform_catenary with Catenary3D as catenary_fn against main_fun.transform_catenary
+    run on that function -- every number on this path is pinned to reference code.
+    Tolerance: the reference's sag is a cosh(h / a) - a cosh(x / a) with the a its (diverging) fixed point ends on, 1e6..1e30
+    for most pairs, i.e. rounding noise in multiples of ulp(a); two libms agree on it to a few ulp of a, not better."""
+    eps = np.finfo(float).eps
+    g = np.load(os.path.join(golden_dir, "kat_catenary_3d.npz"))
+    M = int(g["M"])
+    for L in np.unique(g["rope"]):
+        m = g["rope"] == L
+        got = rv.compute_catenary_3D(g["p0"][m], g["p1"][m], float(L), M)
+        _, a = rv.Catenary3D(float(L), M).batch(g["p0"][m], g["p1"][m])
+        assert got.shape == (int(m.sum()), M, 3)
+        tol = 1e-13 + 8 * eps * np.where(np.isfinite(a), a, 0.0)
+        want = g["points"][m]
+        assert np.array_equal(np.isnan(got), np.isnan(want))       # a pair far shorter than the rope: a overflows, z = inf - inf
+        assert np.all(np.nan_to_num(np.abs(got - want)).max(axis=(1, 2)) <= tol)
+        np.testing.assert_allclose(got[:, :, :2], want[:, :, :2], rtol=1e-14, atol=1e-15)      # x, y carry no sag
+    one = rv.compute_catenary_3D(g["p0"][1], g["p1"][1], float(g["rope"][1]), M)
+    assert one.shape == (M, 3)
+    pts, a = rv.Catenary3D(3.0, M).batch(g["p0"], g["p1"])
+    taut = np.linalg.norm(g["p1"] - g["p0"], axis=1) >= 3.0
+    assert np.array_equal(np.isnan(a), taut) and taut.sum() >= 2
+    with pytest.raises(ValueError):
+        rv.compute_catenary_3D(g["p0"][0], g["p1"][0], 3.0, 1)
+    t = np.load(os.path.join(golden_dir, "kat_transform_catenary_3d.npz"))
+    cat = rv.Catenary3D(float(t["L"]), int(t["M"]))
+    for i in range(len(t["theta"])):
+        r = rv.transform_catenary(t["A"][i], t["B"][i], cat, t["theta"][i], t["gamma"][i])
+        a0 = cat(t["A"][i], t["B"][i])[0]
+        a1 = cat(t["A"][i], r[1][-1])[0]                       # the theta-rotated end point's catenary
+        tol = 1e-12 + 16 * eps * max([0.0] + [v for v in (a0, a1) if np.isfinite(v)])
+        for out, key in zip(r, ("original", "theta_rotated", "theta_aligned", "final")):
+            assert out.shape == t[key][i].shape and np.array_equal(np.isnan(out), np.isnan(t[key][i]))
+            err = np.nan_to_num(np.abs(out - t[key][i])).max()
+            assert err <= tol, (i, key, err, tol)
+
+
 def test_catenary_callable_contract(rv, orc):
     a = np.array([0.1, -0.2, 0.3]); b = np.array([1.2, 0.7, -0.4])
     for frame in ("ENU", "NED"):

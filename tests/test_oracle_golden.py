@@ -92,6 +92,35 @@ def test_transform_catenary(golden_dir):
     assert n_none >= 2      # the straight-segment fallback was exercised
 
 
+def test_compute_catenary_3d_is_the_reference_function(golden_dir):
+    """The in-repo catenary generator (models/catenary_3d.py:5-39): the restatement against the outputs of the reference's
+    own function (tools/make_golden_catenary3d.py), hanging, taut and nearly taut pairs."""
+    g = np.load(os.path.join(golden_dir, "kat_catenary_3d.npz"))
+    M = int(g["M"])
+    straight = 0
+    for i in range(len(g["rope"])):
+        pts = orc.compute_catenary_3d(g["p0"][i], g["p1"][i], float(g["rope"][i]), M)
+        np.testing.assert_allclose(pts, g["points"][i], rtol=1e-13, atol=1e-14)
+        straight += int(np.linalg.norm(g["p1"][i] - g["p0"][i]) >= g["rope"][i])
+    assert straight >= 2                                    # the np.linspace branch was exercised
+    # the script's own demo pair, 12 m of rope over 10 m.  The reference's update a <- a L / (2 a sinh(d / 2a)) multiplies a
+    # by L / arc > 1 for as long as the rope is longer than the arc a implies, so it runs its 100 rounds and ends on a
+    # nearly flat curve (sag 1e-7 m here): that behaviour IS the function, and it is reproduced as it is
+    mid = g["points"][0][M // 2]
+    assert 0.0 < 10.0 - mid[2] < 1e-6
+
+
+def test_transform_catenary_on_reference_code_alone(golden_dir):
+    """main_fun.transform_catenary with the reference's compute_catenary_3D as catenary_fn: no stand-in for the absent
+    pympc class anywhere in the path."""
+    g = np.load(os.path.join(golden_dir, "kat_transform_catenary_3d.npz"))
+    cat = orc.Catenary3D(float(g["L"]), int(g["M"]))
+    for i in range(len(g["theta"])):
+        r = orc.transform_catenary(g["A"][i], g["B"][i], cat, g["theta"][i], g["gamma"][i])
+        for out, key in zip(r, ("original", "theta_rotated", "theta_aligned", "final")):
+            np.testing.assert_allclose(out, g[key][i], rtol=1e-12, atol=1e-13)
+
+
 def test_lowest_z_vec_matches_transform_catenary(golden_dir):
     g = np.load(os.path.join(golden_dir, "kat_transform_catenary.npz"))
     M = int(g["M"])
