@@ -81,6 +81,9 @@ def build_parser():
     ap.add_argument("--model", default="default", help="default | jit-default (reference rows through the hiprtc route) | rows:CT,CG (other Pareto rows) | gen2 | gen3")
     ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid)")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-launched ranks may take")
+    ap.add_argument("--native-check-timeout", type=float, default=90.0,
+                    help="seconds the check of the library's own RCCL path may take at N > 1 before its communicators are aborted "
+                         "and the run continues on torch.distributed's collective")
     ap.add_argument("--fallback-reason", default="", help=argparse.SUPPRESS)   # set by the parent when it re-launches
     return ap
 
@@ -331,14 +334,38 @@ def main():
             # kernels, same slot image -- and the two global records must be the same bits on every rank, with no
             # hand-off time-out.  All ranks agree on the outcome (one all-reduce of a flag); on a failure all of them
             # switch to the torch.distributed collective and the line says why.
-            why = None
+            # A collective that never completes would leave the check (and the run) hanging: a timer thread aborts the
+            # library's communicators after --native-check-timeout seconds (rovmpc_comm_abort = ncclCommAbort; the blocked
+            # synchronise then returns its error), and the GPU-side hand-off waits get a short clock for the check.
+            import threading
+            why, fired = None, []
+
+            def _abort():
+                fired.append(True)
+                try:
+                    eng.comm_abort()
+                except Exception:                         # noqa: BLE001 -- the check reports the time-out either way
+                    pass
+            eng.set_option("handoff_timeout_ms", 3000.0)
+            timer = threading.Timer(args.native_check_timeout, _abort)
+            timer.daemon = True
+            timer.start()
             try:
+                if os.environ.get("ROVMPC_BENCH_TEST_VALIDATE") == "abort":     # test hook: as if the check had timed out
+                    _abort()
                 for i in range(8):
                     got = smpc.step_device(d_state, pools[i % args.pools])
                 smpc.synchronize()
                 got = got.cpu().numpy()
             except Exception as exc:                      # noqa: BLE001 -- recorded in the JSON line
                 why, got = f"native RCCL path failed its check: {exc}", None
+            finally:
+                timer.cancel()
+            if fired:
+                why = (f"native RCCL path did not finish its check within {args.native_check_timeout:.0f} s; its communicators "
+                       f"were aborted" + (f" ({why})" if why else ""))
+                got = None
+            eng.set_option("handoff_timeout_ms", 10000.0)
             ref = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective)
             want = ref.step_device(d_state, pools[7 % args.pools])
             ref.synchronize()

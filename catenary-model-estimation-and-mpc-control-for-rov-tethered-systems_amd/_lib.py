@@ -72,6 +72,7 @@ _SIGNATURES = {
     "rovmpc_comm_join": (C.c_int, [_P, _P]),
     "rovmpc_comm_sync": (C.c_int, [_P, _P]),
     "rovmpc_comm_placement": (C.c_char_p, [_P]),
+    "rovmpc_comm_abort": (C.c_int, [_P]),
     "rovmpc_step_batch_device": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "rovmpc_batch_costs_device": (C.c_int, [_P, C.POINTER(_P)]),
     "rovmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_double]),

@@ -104,6 +104,8 @@ struct rovmpc_handle {
     hipStream_t comm_streams[NCOMM_MAX] = {};
     int ncomm = 0;
     bool comm_placed = false;             // place_comm_streams has run (first rovmpc_step_device_allreduce)
+    bool comm_aborted = false;            // rovmpc_comm_abort: no further collective is issued (guarded by comm_call_mu)
+    std::mutex comm_call_mu;              // the worker's [aborted? -> ncclAllReduce] against rovmpc_comm_abort
     std::string comm_placement;           // what it found (rovmpc_get_info "comm_placement")
     // GPU-side hand-off between the caller's stream and the collective streams (no events on the caller's stream:
     // an event record costs ~3 us and a cross-stream wait ~6 us of its timeline per step, measured):
@@ -1562,6 +1564,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;   // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -1582,6 +1585,7 @@ static const char *rccl_load() {
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))dlsym(lib, "ncclCommAbort");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
     a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
     if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
@@ -1633,8 +1637,13 @@ static void comm_worker(rovmpc_handle *h) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) err = std::string("wait kernel: ") + hipGetErrorString(e);
         if (err.empty()) {
-            ncclResult_t r = g_rccl.AllReduce(h->d_slots[p], h->d_slots[p], (size_t)h->comm_world * R, ncclInt64, ncclMin, comm, cs);
-            if (r != ncclSuccess) err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
+            std::lock_guard<std::mutex> lk(h->comm_call_mu);
+            if (h->comm_aborted || !h->comms[job.c]) {
+                err = "the communicators were aborted (rovmpc_comm_abort)";
+            } else {
+                ncclResult_t r = g_rccl.AllReduce(h->d_slots[p], h->d_slots[p], (size_t)h->comm_world * R, ncclInt64, ncclMin, comm, cs);
+                if (r != ncclSuccess) err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
+            }
         }
         if (err.empty()) {
             hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, cs, (const long long *)h->d_slots[p],
@@ -1919,6 +1928,26 @@ extern "C" int rovmpc_comm_sync(rovmpc_handle *h, void *stream) {
     return take_device_errors(h);
 }
 
+// Callable from ANOTHER thread while steps are in flight (that is its purpose): a collective that never completes -- a peer
+// that died, an ordering fault -- leaves its kernel waiting on the collective stream for ever and rovmpc_comm_sync with
+// it.  ncclCommAbort makes those kernels leave; the GPU-side hand-off waits behind them give up on their own clocks
+// (handoff_timeout_ms), the steps' records carry NaN costs and rovmpc_comm_sync returns its error.  Afterwards the handle
+// issues no collective any more: rovmpc_comm_destroy, then rovmpc_comm_init again or another path.
+extern "C" int rovmpc_comm_abort(rovmpc_handle *h) {
+    if (!h) return ROVMPC_ERR_INVALID;
+    if (!h->comm) return ROVMPC_OK;
+    if (!g_rccl.CommAbort) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "librccl has no ncclCommAbort");
+    ncclComm_t doomed[rovmpc_handle::NCOMM_MAX] = {};
+    {
+        std::lock_guard<std::mutex> lk(h->comm_call_mu);       // the worker is not inside ncclAllReduce while this is held
+        h->comm_aborted = true;
+        for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c) { doomed[c] = h->comms[c]; h->comms[c] = nullptr; }
+    }
+    for (int c = 0; c < rovmpc_handle::NCOMM_MAX; ++c)
+        if (doomed[c]) (void)g_rccl.CommAbort(doomed[c]);      // frees the communicator: no ncclCommDestroy afterwards
+    return ROVMPC_OK;
+}
+
 extern "C" const char *rovmpc_comm_placement(const rovmpc_handle *h) { return h ? h->comm_placement.c_str() : ""; }
 
 extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
@@ -1950,6 +1979,7 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
         (void)hipStreamDestroy(st);
     }
     h->comm_placed = false;
+    h->comm_aborted = false;
     return take_device_errors(h);       // anything raised since the last rovmpc_comm_sync
 }
 

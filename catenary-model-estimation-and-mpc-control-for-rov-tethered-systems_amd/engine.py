@@ -286,6 +286,10 @@ class Engine:
         """Join + synchronise ``stream``; raises ``RovmpcError`` if a GPU-side hand-off of any enqueued step gave up."""
         self._check(self.lib.rovmpc_comm_sync(self._h, stream))
 
+    def comm_abort(self):
+        """ncclCommAbort on the handle's communicators (callable from another thread while a synchronise is stuck)."""
+        self._check(self.lib.rovmpc_comm_abort(self._h))
+
     def comm_placement(self) -> str:
         """One-line report of the collective-stream placement probe (empty before the first sharded step)."""
         v = self.lib.rovmpc_comm_placement(self._h)

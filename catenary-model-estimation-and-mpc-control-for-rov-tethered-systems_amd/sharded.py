@@ -207,5 +207,10 @@ class NativeShardedMPC:
         cur = torch.cuda.current_stream()
         self.engine.comm_sync(cur.cuda_stream)
 
+    def abort(self):
+        """From another thread: make collectives that will never complete let go (``rovmpc_comm_abort``); the stuck
+        ``synchronize`` then raises.  The object is good for ``close()`` only afterwards."""
+        self.engine.comm_abort()
+
     def close(self):
         self.engine.comm_destroy()

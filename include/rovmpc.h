@@ -257,6 +257,11 @@ int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_state, const 
 int rovmpc_comm_join(rovmpc_handle *h, void *stream);
 int rovmpc_comm_sync(rovmpc_handle *h, void *stream);
 int rovmpc_comm_destroy(rovmpc_handle *h);
+/* From another thread, while steps are in flight: ncclCommAbort on the handle's communicators, so that a collective that
+ * will never complete (a dead peer, an ordering fault) lets go of its stream; the hand-off waits behind it time out, the
+ * affected records carry NaN costs, rovmpc_comm_sync returns ROVMPC_ERR_HIP.  The handle issues no collective afterwards
+ * (rovmpc_comm_destroy, then rovmpc_comm_init or another path). */
+int rovmpc_comm_abort(rovmpc_handle *h);
 /* Where the collective streams went.  At the first rovmpc_step_device_allreduce the library probes candidate streams
  * (normal and high priority) against `stream` and against each other and keeps, per communicator, one on which a waiting
  * kernel does not delay kernel completion on the others (two hardware queues on one command-processor pipe do that to

@@ -1011,7 +1011,7 @@ def test_bench_checks_the_native_collective_path_and_records_a_fallback(rv):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = {}
-    for hook in ("1", "fail"):
+    for hook in ("1", "fail", "abort"):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--steps", "20", "--warmup", "5",
                             "--K", "1024", "--no-kernel-timing", "--no-cpu-baseline"],
                            capture_output=True, text=True, timeout=600, env={**base, "ROVMPC_BENCH_TEST_VALIDATE": hook, "MASTER_PORT": "29547"})
@@ -1021,6 +1021,10 @@ def test_bench_checks_the_native_collective_path_and_records_a_fallback(rv):
     assert ok["config"]["collective"].startswith("ncclAllReduce") and ok["config"]["collective_fallback_reason"] is None
     assert bad["config"]["collective"].startswith("torch.distributed") and "failed its check" in bad["config"]["collective_fallback_reason"]
     assert ok["best"] == bad["best"]          # either path ends on the same global record
+    # a check that does not finish: the timer thread aborts the communicators (rovmpc_comm_abort), the run goes on
+    aborted = out["abort"]
+    assert aborted["config"]["collective"].startswith("torch.distributed") and "aborted" in aborted["config"]["collective_fallback_reason"]
+    assert aborted["best"] == ok["best"]
     assert ok["config"]["hw_queues"] == "8"
 
 
