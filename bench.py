@@ -330,7 +330,7 @@ def main():
                 smpc = None
         if smpc is not None and (world > 1 or os.environ.get("ROVMPC_BENCH_TEST_VALIDATE")):
             # The library's own RCCL path cannot run at world > 1 on the one-GPU build box, so every multi-rank run checks it
-            # before timing it: a few steps through it, then the same step through torch.distributed's collective -- same
+            # before timing it: 64 steps through it, then the last of them through torch.distributed's collective -- same
             # kernels, same slot image -- and the two global records must be the same bits on every rank, with no
             # hand-off time-out.  All ranks agree on the outcome (one all-reduce of a flag); on a failure all of them
             # switch to the torch.distributed collective and the line says why.
@@ -353,7 +353,7 @@ def main():
             try:
                 if os.environ.get("ROVMPC_BENCH_TEST_VALIDATE") == "abort":     # test hook: as if the check had timed out
                     _abort()
-                for i in range(8):
+                for i in range(64):                       # many turns of the slot and communicator rotations
                     got = smpc.step_device(d_state, pools[i % args.pools])
                 smpc.synchronize()
                 got = got.cpu().numpy()
@@ -367,7 +367,7 @@ def main():
                 got = None
             eng.set_option("handoff_timeout_ms", 10000.0)
             ref = ShardedMPC(eng, rank=rank, world=world, force_collective=args.force_collective)
-            want = ref.step_device(d_state, pools[7 % args.pools])
+            want = ref.step_device(d_state, pools[63 % args.pools])
             ref.synchronize()
             want = want.cpu().numpy()
             del ref
