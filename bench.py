@@ -393,6 +393,15 @@ def main():
             collective = ("torch.distributed all_reduce(MIN) (nccl backend = RCCL)" if args.backend == "nccl" else
                           "torch.distributed all_reduce(MIN) (gloo, slot image staged through the host: rehearsal)")
     d_res = torch.empty((2 * S, R), dtype=torch.float64, device=dev)
+    hang_guard = None
+    if world > 1 and collective and collective.startswith("ncclAllReduce"):
+        # the checked native path goes on into the measurement; should a collective still never complete there, the run must
+        # end as a failure with a reason, not as a hang: after --launch-timeout / 2 seconds the communicators are aborted
+        # and the blocked synchronise raises
+        import threading
+        hang_guard = threading.Timer(max(60.0, args.launch_timeout / 2), eng.comm_abort)
+        hang_guard.daemon = True
+        hang_guard.start()
 
     # the launch arguments of the plain step are plain integers, taken once: the host side of a timed launch is one ctypes
     # call (a tensor index + data_ptr() per argument costs more than the call)
@@ -465,6 +474,8 @@ def main():
         kev_ms, kev_min_ms, _ = eng.timing_read()
         eng.timing_enable(0)
 
+    if hang_guard is not None:
+        hang_guard.cancel()
     if rank == 0:
         import bench_extras
         units_per_step = world * args.K * args.N
