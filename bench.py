@@ -425,7 +425,7 @@ def main():
 
     # clocks and caches settle over the first few hundred launches (measured: the 20 steps behind 5 warm-ups run 5 % slower
     # than steady state); when --warmup is short, further UNTIMED steps are run in front of it and reported as such
-    presteps = max(0, 200 - args.warmup) if (world == 1 and not args.force_collective) else 0
+    presteps = max(0, 200 - args.warmup) if not args.protocol_only else 0
     # HIP events on the launch stream bracket the timed region: with one fused kernel per step,
     # back to back on one stream, (event span) / steps is the average launch-to-launch period of
     # the rollout kernel (its duration plus the ~1.5 us dependent-launch boundary).
@@ -433,6 +433,8 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     for i in range(presteps + args.warmup):
         one_step(i)
+    if dist is not None:
+        fence(); fence()                      # (the collective library's barrier is slow the first times it runs: 139 us, then 35)
     fence()                                   # barrier + synchronise: the GPU idles only for this one round trip
     t0 = time.perf_counter()
     for e, st in zip(ev0, streams):
