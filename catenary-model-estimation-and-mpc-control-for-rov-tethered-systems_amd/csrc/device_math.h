@@ -200,6 +200,19 @@ RV_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rc
 // a / b on the geometry chains: IEEE in fp64; in fp32 (parity rule: same arg-min or |dJ|/J < 1e-4) one v_rcp_f32 and a
 // multiplication instead of the ten-instruction division sequence
 RV_DEV double m_div(double a, double b) { return a / b; }
+// a / b inside a loaded model's expression (hiprtc path).  The compiler's IEEE sequence is eleven instructions, two of them
+// v_div_scale for operands whose quotient leaves the exponent range; an expression over scaled features of order one does
+// not need those: reciprocal + two Newton steps + one residual correction (<= 1 ulp), and v_div_fixup for the special
+// operands -- x / 0 is still +-inf, 0 / 0 and NaN still NaN, x / inf still 0, as NumPy has them.
+RV_DEV double m_divq(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = ::fma(r, ::fma(-b, r, 1.0), r);
+    r = ::fma(r, ::fma(-b, r, 1.0), r);
+    double q = a * r;
+    q = ::fma(::fma(-b, q, a), r, q);
+    return __builtin_amdgcn_div_fixup(q, b, a);
+}
+RV_DEV float m_divq(float a, float b) { return a / b; }
 RV_DEV float  m_div(float a, float b)  { return a * __builtin_amdgcn_rcpf(b); }
 
 template <typename T> RV_DEV T m_eps();

@@ -464,7 +464,8 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
         case ROVMPC_OP_ADD: bin("+"); break;
         case ROVMPC_OP_SUB: bin("-"); break;
         case ROVMPC_OP_MUL: bin("*"); break;
-        case ROVMPC_OP_DIV: bin("/"); break;
+        case ROVMPC_OP_DIV: { std::string b = st.back(); st.pop_back(); std::string a = st.back();
+                              st.back() = "m_divq(" + a + ", " + b + ")"; break; }
         case ROVMPC_OP_POW: { std::string b = st.back(); st.pop_back(); std::string a = st.back();
                               st.back() = "m_pow(" + a + ", " + b + ")"; break; }
         case ROVMPC_OP_NEG: un("-"); break;

@@ -76,6 +76,28 @@ def test_predict_every_pareto_row(rv, golden_dir, equations, scaler):
             np.testing.assert_allclose(e.predict(g["Xs"], 1), g["out_gamma"][min(i, len(rows_g) - 1)], rtol=1e-12, atol=1e-15)
 
 
+def test_expression_division_keeps_numpy_special_cases(rv):
+    """A loaded model's `/` is a reciprocal with two Newton steps, a residual correction and v_div_fixup (m_divq) instead of
+    the eleven-instruction IEEE sequence: regular quotients to 1 ulp, and x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0, NaN in ->
+    NaN out, exactly as NumPy evaluates the reference's lambdified rows."""
+    rng = np.random.default_rng(3)
+    X = np.zeros((4096, 18))
+    X[:, 0] = rng.standard_normal(4096) * 10.0 ** rng.integers(-6, 7, 4096)
+    X[:, 1] = rng.standard_normal(4096) * 10.0 ** rng.integers(-6, 7, 4096)
+    special = [(1.0, 0.0), (-2.5, 0.0), (0.0, 0.0), (3.0, np.inf), (-3.0, -np.inf), (np.inf, 2.0), (np.nan, 1.0), (1.0, np.nan),
+               (np.inf, np.inf), (0.0, 5.0), (-0.0, 5.0), (1.0, -0.0)]
+    for i, (a, b) in enumerate(special):
+        X[i, 0], X[i, 1] = a, b
+    got = rv.SymbolicRegressor("x0 / x1").predict(X)
+    with np.errstate(all="ignore"):
+        want = X[:, 0] / X[:, 1]
+    n = len(special)
+    assert np.array_equal(np.isnan(got[:n]), np.isnan(want[:n]))
+    assert np.array_equal(got[:n][~np.isnan(want[:n])], want[:n][~np.isnan(want[:n])])          # +-inf, +-0 exactly
+    assert np.array_equal(np.signbit(got[:n][want[:n] == 0]), np.signbit(want[:n][want[:n] == 0]))
+    np.testing.assert_allclose(got[n:], want[n:], rtol=4e-16, atol=0)
+
+
 def test_solve_catenary_and_tension(rv, golden_dir):
     g = np.load(os.path.join(golden_dir, "kat_solve_catenary.npz"))
     C = rv.solve_catenary(g["l"], g["dH"], float(g["L"]))
