@@ -1299,7 +1299,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // velocity-dependent slots of one node from (v, a, unit vector): simply.py:29-31, scaled
             auto vel_slots = [&](T *x, T vx, T vy, T vz, T ax, T ay, T az, T ux, T uy, T uz) {
                 if (uses(13)) {
-                    const T nv = m_sqrt(vx * vx + vy * vy + vz * vz) + T(1e-8);
+                    const T nv = m_sqrtq(vx * vx + vy * vy + vz * vz) + T(1e-8);
                     T ap = (vx * ux + vy * uy + vz * uz) * fast_rcp(nv);      // nv >= 1e-8 (or NaN / inf, which stay that)
                     if (!gen2) ap = m_clip(ap, T(-1), T(1));
                     x[13] = (ap - sMean[apslot]) * sInv[apslot];
