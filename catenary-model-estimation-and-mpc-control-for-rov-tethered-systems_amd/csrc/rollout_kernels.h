@@ -1146,6 +1146,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // the half stages, simulate_rk4_theta_gamma.py:62).  integrator EULER = the reference's explicit double Euler
         // (test_cluster.py:113-129).  State slots 14/15 carry (dtheta, dgamma) at node 0.
         auto integrate_dd = [&]() {
+            const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
             if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
@@ -1159,9 +1160,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * kk.h, h6 = kk.h / T(6);
             T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
             if (VT == ROVMPC_VT_COMPOSE)
-                dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
+                dd_surge_sway<T>(vs_reg * Vx, vs_reg * Vy, vs_reg * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
             auto store_row = [&](int node, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
-                const T row[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
+                const T row[10] = {sway, surge, a_sway, a_surge, vs_reg * vx, vs_reg * vy, vs_reg * vz, vs_reg * ax, vs_reg * ay, vs_reg * az};
 #pragma unroll
                 for (int p = 0; p < 10; ++p)
                     if (uses(p)) RV_PX(p, node, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
@@ -1178,7 +1179,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     V3<T> v = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sg, cg);
                     v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     T sway_n, surge_n;
-                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, RV_PL(sA, 5, n + 1, c), RV_PL(sA, 6, n + 1, c), RV_PL(sA, 7, n + 1, c), sway_n, surge_n);
+                    dd_surge_sway<T>(vs_reg * v.x, vs_reg * v.y, vs_reg * v.z, RV_PL(sA, 5, n + 1, c), RV_PL(sA, 6, n + 1, c), RV_PL(sA, 7, n + 1, c), sway_n, surge_n);
                     const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
                     if (n == 0) store_row(0, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);
                     store_row(n + 1, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
@@ -1403,6 +1404,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
         auto integrate_dd_jit = [&]() {
+            const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
             if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
@@ -1420,13 +1422,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 #pragma unroll
             for (int p = 0; p < 10; ++p) { xa[p] = xb[p] = T(0); if (in_lds(p)) xa[p] = RV_PX(p, 0, c); }
             auto row = [&](T *x, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
-                const T r[10] = {sway, surge, a_sway, a_surge, kk.vs * vx, kk.vs * vy, kk.vs * vz, kk.vs * ax, kk.vs * ay, kk.vs * az};
+                const T r[10] = {sway, surge, a_sway, a_surge, vs_reg * vx, vs_reg * vy, vs_reg * vz, vs_reg * ax, vs_reg * ay, vs_reg * az};
 #pragma unroll
                 for (int p = 0; p < 10; ++p) if (uses(p)) x[p] = (r[p] - sMean[4 + p]) * sInv[4 + p];
             };
             T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
             if (compose_rows)
-                dd_surge_sway<T>(kk.vs * Vx, kk.vs * Vy, kk.vs * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
+                dd_surge_sway<T>(vs_reg * Vx, vs_reg * Vy, vs_reg * Vz, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c), sway_p, surge_p);
             struct Ops { T ktx, kty, kgx, kgy, kgz, u0, u1, u2, ux, uy, uz; };
             Ops opA = {}, opB = {};
             auto fetch_ops = [&](int n, Ops &o) {
@@ -1451,7 +1453,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
                     v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     T sway_n, surge_n;
-                    dd_surge_sway<T>(kk.vs * v.x, kk.vs * v.y, kk.vs * v.z, o.ux, o.uy, o.uz, sway_n, surge_n);
+                    dd_surge_sway<T>(vs_reg * v.x, vs_reg * v.y, vs_reg * v.z, o.ux, o.uy, o.uz, sway_n, surge_n);
                     const T a_sway = (sway_n - sway_p) * inv_hstep, a_surge = (surge_n - surge_p) * inv_hstep;
                     if (n == 0) row(A, sway_p, surge_p, a_sway, a_surge, Vx, Vy, Vz, A0x, A0y, A0z);   // np.gradient's edge rule
                     row(B, sway_n, surge_n, a_sway, a_surge, v.x, v.y, v.z,
