@@ -38,8 +38,15 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 
 // Defined by the run-time generated translation unit (MODEL_JIT only): the two expressions
 // over the 18 scaled feature values of one stage.
-template <typename T> __device__ T jit_f_theta(const T *x);
-template <typename T> __device__ T jit_f_gamma(const T *x);
+// e = the model's stage-invariant subexpressions (jit_exo) on the row the stage reads its exogenous slots from: the
+// generated code hoists every expensive subtree that no state slot enters (rovmpc.hip::bytecode_to_cxx), so that it is
+// evaluated once per row -- end row and midpoint, twice a step -- instead of once per RK4 stage.
+#ifndef ROVMPC_JIT_NSUB
+#define ROVMPC_JIT_NSUB 0
+#endif
+template <typename T> __device__ void jit_exo(const T *x, T *e);
+template <typename T> __device__ T jit_f_theta(const T *x, const T *e);
+template <typename T> __device__ T jit_f_gamma(const T *x, const T *e);
 
 constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
 constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + unit_rel (x,y,z)
@@ -1099,8 +1106,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         } else {
                             x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
                         }
-                        dth = jit_f_theta<T>(x);
-                        dga = jit_f_gamma<T>(x);
+                        T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
+                        jit_exo<T>(x, e);
+                        dth = jit_f_theta<T>(x, e);
+                        dga = jit_f_gamma<T>(x, e);
                         return;
                     }
                     for (int s = 0; s < NEXO; ++s) {
@@ -1198,8 +1207,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                         x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
                         x[14] = x[15] = x[16] = x[17] = T(0);
-                        ddth = jit_f_theta<T>(x);
-                        ddga = jit_f_gamma<T>(x);
+                        T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
+                        jit_exo<T>(x, e);
+                        ddth = jit_f_theta<T>(x, e);
+                        ddga = jit_f_gamma<T>(x, e);
                         return;
                     }
                     for (int p = 0; p < 10; ++p) {
@@ -1338,7 +1349,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // One step: A = row of node n (start), B = row of node n + 1 (end; its velocity slots are built here), o = the
             // step's operands, onext = where the next step's are fetched.  Once the third stage is through, A is dead and
             // takes the row of node n + 2: the next step runs with the roles swapped, so the hand-over is a renaming.
-            auto one_step = [&](int n, T *A, T *B, const Ops &o, Ops &onext) {
+            // the model's stage-invariant subexpressions (jit_exo) on the start row, the end row and their midpoint: the end row
+            // of a step is the start row of the next, stages two and three share the midpoint -- two evaluations per step
+            constexpr int NSUB = ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1;
+            T ea[NSUB], eb[NSUB], em[NSUB];
+            // the slots of a stage that no state enters, from row A (cfrac2 = 0), the midpoint (1), row B (2)
+            auto fill_exo = [&](T *x, const T *A, const T *B, int cfrac2) {
+#pragma unroll
+                for (int sl = 0; sl < NEXO; ++sl)
+                    x[sl] = cfrac2 == 0 ? A[sl] : (cfrac2 == 2 ? B[sl] : (A[sl] + B[sl]) / T(2));   // :62
+                if (gen2) x[16] = x[13];        // simulate_rk4_theta_gamma.py:40: plane 13 carries angle_proj, slot 16 there
+            };
+            auto exo_subs = [&](const T *A, const T *B, int cfrac2, T *e) {
+                if (ROVMPC_JIT_NSUB == 0) return;
+                T x[18];
+#pragma unroll
+                for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
+                fill_exo(x, A, B, cfrac2);
+                jit_exo<T>(x, e);
+            };
+            exo_subs(xa, xb, 0, ea);
+            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
@@ -1347,6 +1378,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     vel_slots(B, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o.ux, o.uy, o.uz);
                     Vx = v.x; Vy = v.y; Vz = v.z;
                 }
+                exo_subs(A, B, 2, eB);
+                if (!euler) exo_subs(A, B, 1, em);
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
                 const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;
                 auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
@@ -1355,12 +1388,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
                     else { p16 = (s16a + s16b) / T(2); p17 = (s17a + s17b) / T(2); }
                     T x[18];
-#pragma unroll
-                    for (int sl = 0; sl < NEXO; ++sl)
-                        x[sl] = cfrac2 == 0 ? A[sl] : (cfrac2 == 2 ? B[sl] : (A[sl] + B[sl]) / T(2));   // :62
+                    fill_exo(x, A, B, cfrac2);
+                    const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
                     if (gen2) {
                         // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
-                        x[16] = x[13];
                         x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
                         T s_t = st, c_t = ct, s_g = sg, c_g = cg;        // first stage: the node state itself
                         if (cfrac2 != 0) sincos_near2(yth, th, st, ct, s_t, c_t, yga, ga, sg, cg, s_g, c_g);
@@ -1369,8 +1400,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     } else {
                         x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
                     }
-                    dth = jit_f_theta<T>(x);
-                    dga = jit_f_gamma<T>(x);
+                    dth = jit_f_theta<T>(x, e);
+                    dga = jit_f_gamma<T>(x, e);
                 };
                 T k1t, k1g;
                 stage(th, ga, 0, k1t, k1g);
@@ -1398,8 +1429,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             int n = 0;
-            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
-            if (n < nsteps) one_step(n, xa, xb, opA, opB);
+            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB); one_step(n + 1, xb, xa, eb, ea, opB, opA); }
+            if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB);
         };
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
@@ -1446,7 +1477,23 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (nsteps > 0) { fetch_ops(0, opA); fetch_rows(1, xb); }
             T st = T(0), ct = T(1), sg = T(0), cg = T(1);
             if (compose_rows) { m_sincos(y0, &st, &ct); m_sincos(y1, &sg, &cg); }
-            auto one_step = [&](int n, T *A, T *B, const Ops &o, Ops &onext) {
+            constexpr int NSUB = ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1;
+            T ea[NSUB], eb[NSUB], em[NSUB];           // as in integrate_jit
+            auto fill_exo = [&](T *x, const T *A, const T *B, int cfrac2) {
+#pragma unroll
+                for (int p = 0; p < 10; ++p)
+                    x[4 + p] = cfrac2 == 0 ? A[p] : (cfrac2 == 2 ? B[p] : (A[p] + B[p]) / T(2));
+                x[14] = x[15] = x[16] = x[17] = T(0);
+            };
+            auto exo_subs = [&](const T *A, const T *B, int cfrac2, T *e) {
+                if (ROVMPC_JIT_NSUB == 0) return;
+                T x[18];
+                x[0] = x[1] = x[2] = x[3] = T(0);
+                fill_exo(x, A, B, cfrac2);
+                jit_exo<T>(x, e);
+            };
+            bool ea_ready = false;
+            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
@@ -1460,16 +1507,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep);
                     Vx = v.x; Vy = v.y; Vz = v.z; sway_p = sway_n; surge_p = surge_n;
                 }
+                // (row A of the first step is complete only here: np.gradient's edge rule needs the first step's end row)
+                if (!ea_ready) { exo_subs(A, B, 0, eA); ea_ready = true; }
+                exo_subs(A, B, 2, eB);
+                if (!euler) exo_subs(A, B, 1, em);
                 auto stage = [&](T s0, T s1, T s2, T s3, int cfrac2, T &ddth, T &ddga) {
                     T x[18];
-#pragma unroll
-                    for (int p = 0; p < 10; ++p)
-                        x[4 + p] = cfrac2 == 0 ? A[p] : (cfrac2 == 2 ? B[p] : (A[p] + B[p]) / T(2));
+                    fill_exo(x, A, B, cfrac2);
+                    const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
                     x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                     x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
-                    x[14] = x[15] = x[16] = x[17] = T(0);
-                    ddth = jit_f_theta<T>(x);
-                    ddga = jit_f_gamma<T>(x);
+                    ddth = jit_f_theta<T>(x, e);
+                    ddga = jit_f_gamma<T>(x, e);
                 };
                 T a1t, a1g;
                 stage(y0, y1, y2, y3, 0, a1t, a1g);
@@ -1502,8 +1551,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             int n = 0;
-            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, opA, opB); one_step(n + 1, xb, xa, opB, opA); }
-            if (n < nsteps) one_step(n, xa, xb, opA, opB);
+            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB); one_step(n + 1, xb, xa, eb, ea, opB, opA); }
+            if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB);
         };
         const bool wide = NT > nint;
         if (tid < nint) {

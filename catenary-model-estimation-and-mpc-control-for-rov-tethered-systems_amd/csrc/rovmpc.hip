@@ -449,42 +449,80 @@ static std::string fmt_const(double v) {
     return "T(" + t + ")";
 }
 
-static std::string bytecode_to_cxx(const int32_t *code, int n, const double *consts) {
-    std::vector<std::string> st;
+// C++ text of one expression.  Stage-invariant subexpressions are hoisted: of the 18 slots a stage sees, only the state
+// slots (`state_mask`) change between the four RK4 stages of a step; everything else comes from the row of a node (start,
+// end) or their midpoint, the end row of one step is the start row of the next, and stages two and three share the
+// midpoint.  A maximal subtree without a state slot that holds at least one expensive operation (sin, cos, tanh, exp, log,
+// sqrt, pow, a division) is therefore emitted once into `subs` -- evaluated per ROW, twice per step instead of four times --
+// and referenced as e[k]; `a / D` with a stage-invariant D becomes a * e[k], e[k] = 1 / D (one more rounding, <= 1.5 ulp).
+// Both expressions share the list (identical subtrees get one entry); at most ROVMPC_MAX_SUBS of them, the rest stay inline.
+constexpr int ROVMPC_MAX_SUBS = 8;
+static std::string bytecode_to_cxx(const int32_t *code, int n, const double *consts, unsigned state_mask = 0xffffffffu,
+                                   std::vector<std::string> *subs = nullptr) {
+    struct Item { std::string text; bool exo; int heavy; bool leaf; };
+    std::vector<Item> st;
+    auto hoist = [&](Item &it) {            // replace a stage-invariant, expensive subtree by e[k]
+        if (!subs || !it.exo || it.heavy == 0) return;
+        int k = -1;
+        for (size_t q = 0; q < subs->size(); ++q) if ((*subs)[q] == it.text) k = (int)q;
+        if (k < 0) {
+            if ((int)subs->size() >= ROVMPC_MAX_SUBS) return;
+            subs->push_back(it.text); k = (int)subs->size() - 1;
+        }
+        it.text = "e[" + std::to_string(k) + "]"; it.heavy = 0; it.leaf = true;
+    };
     for (int pc = 0; pc < n; ++pc) {
         const int op = code[pc] & 0xff, arg = code[pc] >> 8;
-        auto un = [&](const char *f) { std::string a = st.back(); st.back() = std::string(f) + "(" + a + ")"; };
-        auto bin = [&](const char *o) {
-            std::string b = st.back(); st.pop_back();
-            std::string a = st.back(); st.back() = "(" + a + " " + o + " " + b + ")";
+        auto un = [&](const char *f, int cost) {
+            Item &a = st.back();
+            a.text = std::string(f) + "(" + a.text + ")"; a.heavy += cost; a.leaf = false;
         };
+        auto bin = [&](const char *pre, const char *mid, const char *post, int cost) {
+            Item b = st.back(); st.pop_back();
+            Item &a = st.back();
+            if (a.exo != b.exo) { hoist(a.exo ? a : b); }      // the invariant side ends here: it is maximal
+            a.text = std::string(pre) + a.text + mid + b.text + post;
+            a.exo = a.exo && b.exo; a.heavy += b.heavy + cost; a.leaf = false;
+        };
+        const size_t need = op <= ROVMPC_OP_PUSH_F ? 0 : ((op >= ROVMPC_OP_ADD && op <= ROVMPC_OP_DIV) || op == ROVMPC_OP_POW) ? 2 : 1;
+        if (st.size() < need) return "m_nan<T>()";          // (validate_code has already checked the stack discipline)
         switch (op) {
-        case ROVMPC_OP_PUSH_C: st.push_back(fmt_const(consts[arg])); break;
-        case ROVMPC_OP_PUSH_F: st.push_back("x[" + std::to_string(arg) + "]"); break;
-        case ROVMPC_OP_ADD: bin("+"); break;
-        case ROVMPC_OP_SUB: bin("-"); break;
-        case ROVMPC_OP_MUL: bin("*"); break;
-        case ROVMPC_OP_DIV: { std::string b = st.back(); st.pop_back(); std::string a = st.back();
-                              st.back() = "m_divq(" + a + ", " + b + ")"; break; }
-        case ROVMPC_OP_POW: { std::string b = st.back(); st.pop_back(); std::string a = st.back();
-                              st.back() = "m_pow(" + a + ", " + b + ")"; break; }
-        case ROVMPC_OP_NEG: un("-"); break;
-        case ROVMPC_OP_SIN: un("m_sin"); break;
-        case ROVMPC_OP_COS: un("m_cos"); break;
-        case ROVMPC_OP_TANH: un("m_tanh"); break;
-        case ROVMPC_OP_ABS: un("m_abs"); break;
-        case ROVMPC_OP_SQUARE: un("rv_sq"); break;
-        case ROVMPC_OP_EXP: un("m_exp"); break;
-        case ROVMPC_OP_LOG: un("m_log"); break;
-        case ROVMPC_OP_SQRT: un("m_sqrt"); break;
+        case ROVMPC_OP_PUSH_C: st.push_back({fmt_const(consts[arg]), true, 0, true}); break;
+        case ROVMPC_OP_PUSH_F: st.push_back({"x[" + std::to_string(arg) + "]", arg < 32 && !((state_mask >> arg) & 1u), 0, true}); break;
+        case ROVMPC_OP_ADD: bin("(", " + ", ")", 0); break;
+        case ROVMPC_OP_SUB: bin("(", " - ", ")", 0); break;
+        case ROVMPC_OP_MUL: bin("(", " * ", ")", 0); break;
+        case ROVMPC_OP_DIV: {
+            Item &b = st.back(), &a = st[st.size() - 2];
+            const bool b_const = b.leaf && b.text.compare(0, 2, "T(") == 0;
+            if (subs && b.exo && !a.exo && !b_const) {          // a / D, D stage-invariant: a * (1 / D), the reciprocal per row
+                Item r = {"m_divq(T(1), " + b.text + ")", true, b.heavy + 1, false};
+                hoist(r);
+                if (r.leaf) { b = r; bin("(", " * ", ")", 0); break; }
+            }
+            bin("m_divq(", ", ", ")", 1);
+            break;
+        }
+        case ROVMPC_OP_POW: bin("m_pow(", ", ", ")", 1); break;
+        case ROVMPC_OP_NEG: un("-", 0); break;
+        case ROVMPC_OP_SIN: un("m_sin", 1); break;
+        case ROVMPC_OP_COS: un("m_cos", 1); break;
+        case ROVMPC_OP_TANH: un("m_tanh", 1); break;
+        case ROVMPC_OP_ABS: un("m_abs", 0); break;
+        case ROVMPC_OP_SQUARE: un("rv_sq", 0); break;
+        case ROVMPC_OP_EXP: un("m_exp", 1); break;
+        case ROVMPC_OP_LOG: un("m_log", 1); break;
+        case ROVMPC_OP_SQRT: un("m_sqrt", 1); break;
         case ROVMPC_OP_POWI: { const int e = arg >= (1 << 23) ? arg - (1 << 24) : arg;
-                               std::string a = st.back(); st.back() = "rv_powi(" + a + ", " + std::to_string(e) + ")"; break; }
-        case ROVMPC_OP_SAFE_LOG: { std::string a = st.back(); st.back() = "m_log(m_abs(" + a + ") + T(1e-5))"; break; }
-        case ROVMPC_OP_SAFE_SQRT: { std::string a = st.back(); st.back() = "m_sqrt(m_abs(" + a + "))"; break; }
+                               Item &a = st.back(); a.text = "rv_powi(" + a.text + ", " + std::to_string(e) + ")"; a.heavy += (e < 0); a.leaf = false; break; }
+        case ROVMPC_OP_SAFE_LOG: { Item &a = st.back(); a.text = "m_log(m_abs(" + a.text + ") + T(1e-5))"; a.heavy += 1; a.leaf = false; break; }
+        case ROVMPC_OP_SAFE_SQRT: { Item &a = st.back(); a.text = "m_sqrt(m_abs(" + a.text + "))"; a.heavy += 1; a.leaf = false; break; }
         default: return "m_nan<T>()";
         }
     }
-    return st.empty() ? "m_nan<T>()" : st.back();
+    if (st.empty()) return "m_nan<T>()";
+    hoist(st.back());                                          // an expression that no stage state enters at all
+    return st.back().text;
 }
 
 struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_loop = nullptr, fn_step = nullptr; };
@@ -537,22 +575,34 @@ static hipFunction_t jit_build(int device, const std::string &src, std::string &
 static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
                               const double *consts) {
     const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
+    // the slots a stage sets itself (everything else is a row of a node, or the midpoint of two)
+    const unsigned state_mask = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 0xf000u        // theta, gamma, cos theta, sin gamma
+                              : h->cfg.feature_map == ROVMPC_FEATURES_GEN3 ? 0x3c00fu       // theta, gamma, their rates (+ the unused tail)
+                                                                           : 0x3c000u;      // x14..x17: state and delay slots
+    std::vector<std::string> subs;
+    const std::string f_th = bytecode_to_cxx(code_th, n_th, consts, state_mask, getenv("ROVMPC_JIT_NO_HOIST") ? nullptr : &subs);
+    const std::string f_ga = bytecode_to_cxx(code_ga, n_ga, consts, state_mask, getenv("ROVMPC_JIT_NO_HOIST") ? nullptr : &subs);
     std::string s;
     s += "#define ROVMPC_JIT_FMAP " + std::to_string(h->cfg.feature_map) + "\n";
+    s += "#define ROVMPC_JIT_NSUB " + std::to_string(subs.size()) + "\n";
     s += "#define ROVMPC_JIT_USED " + std::to_string(h->used_planes) + "u\n#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
     s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
     s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
          "while (ae) { if (ae & 1) r *= b; b *= b; ae >>= 1; } return e < 0 ? T(1) / r : r; }\n";
-    s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x) { typedef " + real +
-         " T; return " + bytecode_to_cxx(code_th, n_th, consts) + "; }\n";
-    s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x) { typedef " + real +
-         " T; return " + bytecode_to_cxx(code_ga, n_ga, consts) + "; }\n";
+    s += std::string("template <> __device__ void jit_exo<") + real + ">(const " + real + " *x, " + real + " *e) { typedef " + real + " T; (void)x; (void)e;";
+    for (size_t k = 0; k < subs.size(); ++k) s += " e[" + std::to_string(k) + "] = " + subs[k] + ";";
+    s += " }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x, const " + real + " *e) { typedef " + real +
+         " T; (void)e; return " + f_th + "; }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e) { typedef " + real +
+         " T; (void)e; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a, p);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", true>(a, p);\n}\n";
+    if (getenv("ROVMPC_JIT_DUMP")) fprintf(stderr, "[rovmpc] hiprtc translation unit:\n%s\n", s.c_str());
     return s;
 }
 
