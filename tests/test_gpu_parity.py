@@ -76,6 +76,34 @@ def test_predict_every_pareto_row(rv, golden_dir, equations, scaler):
             np.testing.assert_allclose(e.predict(g["Xs"], 1), g["out_gamma"][min(i, len(rows_g) - 1)], rtol=1e-12, atol=1e-15)
 
 
+def test_hoisted_subexpressions_do_not_change_the_rollout(rv):
+    """The hiprtc path evaluates a model's stage-invariant subexpressions once per row instead of once per RK4 stage
+    (bytecode_to_cxx / jit_exo).  With the hoisting switched off (ROVMPC_JIT_NO_HOIST) the same models give the same costs and
+    the same winner, to rounding: a hoisted product no longer contracts into the FMA around it, a hoisted divisor is applied as
+    a reciprocal."""
+    cases = [("gen2", rv.generation2_model(), rv.FEATURES_GEN2), ("gen3", rv.generation3_model(), rv.FEATURES_GEN3),
+             ("reference rows", rv.default_model(), rv.FEATURES_GEN1), ("rows 16/20", rv.default_model(16, 20), rv.FEATURES_GEN1)]
+    for name, model, fmap in cases:
+        out = {}
+        for hoist in (True, False):
+            if hoist:
+                os.environ.pop("ROVMPC_JIT_NO_HOIST", None)
+            else:
+                os.environ["ROVMPC_JIT_NO_HOIST"] = "1"
+            try:
+                cfg = rv.MPCConfig(N=20, K=512, feature_map=fmap, no_builtin=True)
+                state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=77)
+                with rv.Engine(cfg, model) as e:
+                    assert e.model_path == "jit", name
+                    out[hoist] = (e.step(state, U), e.rollout_costs(state, U))
+            finally:
+                os.environ.pop("ROVMPC_JIT_NO_HOIST", None)
+        (ra, Ja), (rb, Jb) = out[True], out[False]
+        assert ra.index == rb.index, name
+        np.testing.assert_allclose(Ja, Jb, rtol=1e-11, err_msg=name)
+        np.testing.assert_allclose(ra.traj, rb.traj, rtol=1e-11, atol=1e-14, err_msg=name)
+
+
 def test_expression_division_keeps_numpy_special_cases(rv):
     """A loaded model's `/` is a reciprocal with two Newton steps, a residual correction and v_div_fixup (m_divq) instead of
     the eleven-instruction IEEE sequence: regular quotients to 1 ulp, and x / 0 = +-inf, 0 / 0 = NaN, x / inf = 0, NaN in ->
