@@ -198,9 +198,10 @@ RV_DEV double fast_rcp(double x) {
     return ::fma(r, ::fma(-x, r, 1.0), r);
 }
 RV_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32: 1 ulp
-// a / b on the geometry chains: IEEE in fp64; in fp32 (parity rule: same arg-min or |dJ|/J < 1e-4) one v_rcp_f32 and a
-// multiplication instead of the ten-instruction division sequence
-RV_DEV double m_div(double a, double b) { return a / b; }
+// a / b on the geometry chains: in fp64 the nine-instruction quotient of m_divq below; in fp32 (parity rule: same arg-min or
+// |dJ|/J < 1e-4) one v_rcp_f32 and a multiplication instead of the ten-instruction division sequence
+RV_DEV double m_divq(double a, double b);
+RV_DEV double m_div(double a, double b) { return m_divq(a, b); }      // (1 ulp, special operands as IEEE: see m_divq)
 // a / b inside a loaded model's expression (hiprtc path).  The compiler's IEEE sequence is eleven instructions, two of them
 // v_div_scale for operands whose quotient leaves the exponent range; an expression over scaled features of order one does
 // not need those: reciprocal + two Newton steps + one residual correction (<= 1 ulp), and v_div_fixup for the special
@@ -335,7 +336,7 @@ RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_l
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const T L2 = L * L - dH[s] * dH[s];
-        const T sq = m_sqrt(L2);
+        const T sq = m_sqrtq(L2);
         r[s] = m_div(sq, l[s]);
         rm1[s] = m_div(L2 - l[s] * l[s], l[s] * (sq + l[s]));
         const bool warm = u_warm && u_warm[s] > T(0) && ch_warm[s] > r[s] && rm1[s] > T(0) && m_finite(r[s]);
@@ -437,7 +438,7 @@ RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T theta, T g
     const T omc = T(1) - cg;
     const V3<T> r3 = {-kg.y * sg + omc * kg.z * kg.x, kg.x * sg + omc * kg.z * kg.y, cg + omc * kg.z * kg.z};
     a.m = rodrigues_flat(r3, kt.x, kt.y, st, ct);
-    a.lp = m_sqrt(a.Bp.x * a.Bp.x + a.Bp.y * a.Bp.y);
+    a.lp = m_sqrtq(a.Bp.x * a.Bp.x + a.Bp.y * a.Bp.y);
     a.dHp = up * a.Bp.z;
     return a;
 }
@@ -451,7 +452,7 @@ RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) 
     if (c.C == c.C) {
         // a valid root means L^2 - dH'^2 > l'^2 > 0: every quantity inverted below is finite and positive
         const T eu = m_exp(c.u);
-        T E = m_sqrt(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(eu);    // e^{a}
+        T E = m_sqrtq(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(eu);    // e^{a}
         T Ei = fast_rcp(E);
         const T invden = m_div(T(1), T(M - 1));
         const T Ed = m_exp(T(2) * c.u * invden), Edi = fast_rcp(Ed);

@@ -825,15 +825,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T rx = RV_PL(sP, 0, n + 1, c) - P0x, ry = RV_PL(sP, 1, n + 1, c) - P0y,
                     rz = RV_PL(sP, 2, n + 1, c) - P0z;
             const T *u = &sU[c * US + n * 3];
-            const T l = m_sqrt(rx * rx + ry * ry);                               // main_fun.py:292
+            const T l = m_sqrtq(rx * rx + ry * ry);                              // main_fun.py:292
             const T dH = kk.up * rz;                                              // :293
-            const T d = m_sqrt(rx * rx + ry * ry + rz * rz);
+            const T d = m_sqrtq(rx * rx + ry * ry + rz * rz);
             const CatRoot<T> cr = solve_catenary_root<T>(l, dH, kk.L, kk.c_lo, kk.c_hi);   // :303
             const T Tn = cable_tension<T>(l, cr, kk.w_per_len);                   // :304-305
             {
                 const T shu = cr.r * cr.u;                                        // sinh u at the root
                 sW[n * CK + c] = (cr.C == cr.C) ? cr.u : T(-1);
-                sW[(N + n) * CK + c] = m_sqrt(T(1) + shu * shu);
+                sW[(N + n) * CK + c] = m_sqrtq(T(1) + shu * shu);
             }
             const T e0 = u[0] - kk.Uref[0], e1 = u[1] - kk.Uref[1], e2 = u[2] - kk.Uref[2];
             const T taut = m_max(T(0), d - kk.rhoL);
