@@ -933,8 +933,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const bool bounded = s_prog[0] == 0 && Trig<T>::bounded(m_abs(X3[0]));   // every sine argument of the loop is below the fast-path limit
             // sincos(theta_n) for the velocity transform.  theta moves by |d| ~ 1e-4 per step, so
             // after a full evaluation at step 0 (and every 16th step, or whenever a lane's |d|
-            // reaches 2^-8) the pair is advanced by the angle-addition formulas with the odd/even
-            // Taylor polynomials of d to d^5 / d^6 (truncation < 1e-18 there).
+            // reaches 2^-7) the pair is advanced by the angle-addition formulas with the odd/even
+            // Taylor polynomials of d to d^5 / d^6 (truncation < 4e-19 there).
             T st = T(0), ct = T(1);
             if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th0, &st, &ct);
             // One loop for the common mode (RK4, interpolated delay slot, bounded sine arguments) with its flags
@@ -967,9 +967,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
                     // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
                     const T dlt = thn - th;
-                    const bool big = !(m_abs(dlt) < T(0.00390625));
+                    const bool big = !(m_abs(dlt) < T(0.0078125));
                     auto advance = [&]() {
-                        // |d| < 2^-8: the first neglected terms are d^7 / 5040 and d^8 / 40320, below 1e-18 relative
+                        // |d| < 2^-7: the first neglected terms, d^7 / 5040 and d^8 / 40320, are below 4e-19 (absolute, of
+                        // values of size one): sixteen steps between two anchors add up to less than 1e-17
                         const T d2 = dlt * dlt;
                         const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20)));
                         const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30)));
@@ -1261,7 +1262,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         //  * the operands of step n + 1 (axes, control, unit vector, state-independent rows) are fetched during step n;
         //  * sincos(theta_n), sincos(gamma_n) -- velocity transform, generation-2 slots cos(theta) / sin(gamma) at the
         //    stage states -- advance by the angle-addition formulas from the previous evaluation (odd / even Taylor
-        //    polynomials of the increment to d^5 / d^6, truncation < 5e-17 for |d| < 2^-7), re-anchored by a full
+        //    polynomials of the increment to d^5 / d^6, truncation < 4e-19 for |d| < 2^-7), re-anchored by a full
         //    evaluation every 16 steps and for any lane whose increment is larger (wave-uniform choice, per-lane
         //    result: a candidate's arithmetic never depends on its neighbours).
         auto add_angle = [](T s0, T c0, T d, T &s, T &c) {
