@@ -63,8 +63,9 @@ RV_DEV void fast_sincos_k(double x, const TrigK &K, double *s, double *c) {
     const double cr = w + (((1.0 - w) - hz) + z * z * pc);
     const int q = (int)k;
     const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
-    *s = (q & 2) ? -ss : ss;
-    *c = ((q + 1) & 2) ? -cc : cc;
+    // signs: bit 1 of q (sine), bit 1 of q + 1 (cosine) into the sign bit
+    *s = __hiloint2double(__double2hiint(ss) ^ (int)(((unsigned)q & 2u) << 30), __double2loint(ss));
+    *c = __hiloint2double(__double2hiint(cc) ^ (int)(((unsigned)(q + 1) & 2u) << 30), __double2loint(cc));
 }
 RV_DEV void fast_sincos_f64(double x, double *s, double *c) { fast_sincos_k(x, trig_constants(false), s, c); }
 
@@ -95,7 +96,8 @@ RV_DEV double fast_sin_k(double x, const SinK &K) {
     #pragma unroll
     for (int i = 6; i >= 0; --i) p = ::fma(p, z, K.c[i]);
     const double v = ::fma(r * z, p, r);
-    return ((int)k & 1) ? -v : v;
+    // sign (-1)^k: bit 0 of k into the sign bit (three instructions; the select form takes five)
+    return __hiloint2double(__double2hiint(v) ^ (int)((unsigned)(int)k << 31), __double2loint(v));
 }
 // fp32 (BASELINE config 3).  The device library's sinf / sincosf inline a Payne-Hanek reduction beside every call and
 // evaluate both polynomials for either result: ~40 instructions and six mask operations on the hot path, twice the fp64
@@ -484,7 +486,9 @@ RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) 
 // sequential phase: ds_bpermute ~150 cycles per exchange, v_permlane16/32_swap rows slower still.)
 template <int J> RV_DEV unsigned quad_bcast_u32(unsigned v) {
     constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);          // quad_perm:[J,J,J,J]
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
+    // (mov_dpp: every lane of a full quad has a source, so the destination needs no prior value -- update_dpp with an
+    // `old` operand costs a v_mov per use to materialise it)
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, ctrl, 0xf, 0xf, false);
 }
 RV_DEV void quad4(double v, double (&out)[4]) {
     const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
