@@ -908,6 +908,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T m3 = sMean[3], i3 = sInv[3], m16 = sMean[16], i16 = sInv[16];
             const T KT = T(0.048152514);
             const T hKT = euler ? kk.h * KT : (kk.h / T(6)) * KT;
+            const T K16a = T(3) * i16, K16b = T(-6) * m16 * i16;
             if (PERSIST && a.wait_theta) {
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); thm0 = ring_get(2); }
@@ -945,7 +946,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 const T thm = TH[p], th = TH[q], x3a = X3[p], sinXa = SX[p];
                 const T x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
                 const T Gn = GG[p];
-                if (n + 1 < nsteps) fetch(n + 1, q);
+                // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
+                // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
+                if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
                 const T x3s = x3a + x3b;
                 const T x3m = x3s / T(2);                                  // :62 feature midpoint
                 const T sarg = (role & 1) ? x3m : x3b;
@@ -959,7 +962,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (eul) {
                     S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
                 } else {
-                    const T s16 = hld ? T(6) * s16a : T(3) * (((thm + th) - T(2) * m16) * i16);
+                    // 3 (s16a + s16b) = 3 ((thm + th) - 2 m16) / scale16, as one FMA on the chain (constants hoisted: K16a, K16b)
+                    const T s16 = hld ? T(6) * s16a : (thm + th) * K16a + K16b;
                     S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
                 }
                 const T thn = th + hKT * S;
