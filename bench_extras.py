@@ -129,7 +129,7 @@ def run_extras(out, args, cfg, model, dev):
         table = {}
         for feedback in (True, False):
             runs = {}
-            for mode in ("per_step", "pipelined", "persistent"):
+            for mode in ("per_step", "pipelined"):
                 try:
                     run_closed_loop(eng3, 12, min(T, 200), feedback=feedback, mode=mode)            # warm-up
                     rep = run_closed_loop(eng3, 12, T, feedback=feedback, mode=mode)
@@ -151,7 +151,7 @@ def run_extras(out, args, cfg, model, dev):
                                       "i's winner -- the steps are truly sequential (and the chosen rows' gamma recurrence drifts over "
                                       "10 000 fed-back steps: costs grow, parity is the bar, not plausibility); measured_rows: every step "
                                       "takes its whole state from the trajectory table.  per_step = one launch per step on one stream; "
-                                      "pipelined = one launch per step on two streams with the state handed over on the GPU; persistent = "
-                                      "one launch for all steps; batched_replay (measured rows only) = 8 consecutive steps per "
+                                      "pipelined = one launch per step on two streams with the state handed over on the GPU; "
+                                      "batched_replay (measured rows only) = 8 consecutive steps per "
                                       "batched launch.  real_time_factor = steps * dt / wall"}
         eng3.close()

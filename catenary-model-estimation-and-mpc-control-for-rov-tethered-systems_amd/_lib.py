@@ -79,7 +79,6 @@ _SIGNATURES = {
     "rovmpc_device_status": (C.c_int, [_P]),
     "rovmpc_comm_destroy": (C.c_int, [_P]),
     "rovmpc_closed_loop_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
-    "rovmpc_closed_loop_persistent_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "rovmpc_closed_loop_pipelined_device": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, _P, _P]),
     "rovmpc_timing_enable": (C.c_int, [_P, C.c_int32]),
     "rovmpc_timing_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

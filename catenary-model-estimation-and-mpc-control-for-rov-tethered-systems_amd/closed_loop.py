@@ -71,8 +71,7 @@ def velocity_prior(engine: Engine):
 
 
 def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_pools: int = 8,
-                    seed: int = 0, k_offset: int = 0, feedback: bool = False, persistent: bool = False,
-                    mode: str = "") -> ClosedLoopReport:
+                    seed: int = 0, k_offset: int = 0, feedback: bool = False, mode: str = "") -> ClosedLoopReport:
     """Runs the loop on ``engine``'s device.  If the engine has a native communicator
     (``Engine.comm_init``) every step is the candidate-sharded one.  ``feedback=True`` replaces the
     measured (theta, gamma) by the model's own first predicted node from the second step on."""
@@ -105,7 +104,7 @@ def run_closed_loop(engine: Engine, exp_case: int = 12, n_steps: int = 1000, n_p
             i += B
     else:
         engine.closed_loop_device(exo.data_ptr(), n_steps, state.data_ptr(), pools.data_ptr(), n_pools, results.data_ptr(),
-                                  k_offset, feedback, stream.cuda_stream, persistent=persistent, mode=mode)
+                                  k_offset, feedback, stream.cuda_stream, mode=mode)
     torch.cuda.synchronize()
     wall = _time.perf_counter() - t_start
     res = results.cpu().numpy()

@@ -92,7 +92,7 @@ template <typename T> struct RolloutArgs {
     const double *plant_next;     // 16 doubles, the measured row of step i + 1
     double *plant_state;          // the state the next launch reads
     int plant_feedback;           // 1: keep the model's own (theta, gamma) = first predicted node of this step's winner
-    // Closed loop with the state handed over on the GPU (closed_loop_kernel / closed_loop_step_kernel; ring == null otherwise).
+    // Closed loop with the state handed over on the GPU (closed_loop_step_kernel; ring == null otherwise).
     // Step g takes P0, P1, V1, A1 from its measured row exo_cur -- known before the loop starts -- and, with feedback and
     // g > 0, (theta0, gamma0, theta_prev, gamma_prev) from ring[g & 3][4], which the sweeper of step g - 1 fills: gamma0 /
     // gamma_prev EARLY (compiled-in model: gamma's path is candidate-invariant, so gamma_1 is known once that sweeper's own
@@ -103,7 +103,7 @@ template <typename T> struct RolloutArgs {
     unsigned long long *seq_theta, *seq_gamma;
     long long step;               // g
     int from_ring;                // feedback && g > 0: (theta, gamma) come from the ring, else from exo_cur[12..15]
-    int wait_theta;               // wait for seq_theta >= g before the theta chain (from_ring, or back-pressure of the in-launch loop)
+    int wait_theta;               // wait for seq_theta >= g before the theta chain (== from_ring)
     int publish;                  // g + 1 < T: the sweeper publishes for step g + 1
     int NT, nblocks;              // launch geometry (blockDim / gridDim are dependent loads through the implicit arguments)
     int ck_shift;                 // CK == 1 << ck_shift (workgroup sizes are powers of two)
@@ -242,8 +242,8 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     // is pending -- no ticket counter, no fence, and the other workgroups leave as soon as they have published.
     {
         int j = 0;
-        // 60 s of the 100 MHz clock; inside the persistent loop the hand-off timeout (a workgroup that gave up its own wait
-        // never publishes, and the grid has to drain)
+        // 60 s of the 100 MHz clock; in the closed loop with GPU-side hand-off the hand-off timeout (both grids in flight
+        // have to drain)
         const unsigned long long give_up = wall_clock64() + (a.ring ? a.handoff_ticks : 6000000000ULL);
         for (unsigned it = 1;; ++it) {
             bool pending = false;
@@ -434,25 +434,17 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 // LEAN: the plain single-problem step (rovmpc_step_device and the host-pointer entry points): one problem, no slot image,
 // no hand-off flags, no host mirror, no plant update -- those branches are compiled out (measured on one box: the full
 // kernel is 0.3 us slower per C2 step than the round-1 kernel, which had none of them).
-template <typename T, int MODEL, int VT, bool PERSIST = false, bool LEAN = false, bool SAMPLE = false>
+template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
-    // Inside the persistent loop the roots of every index, address and bound below are made opaque once per step
-    // (empty asm): otherwise the optimiser hoists the step-invariant part of the whole body out of the step loop and
-    // keeps it live across it (measured: 256 VGPRs + scratch instead of 148).
-    auto opaque_s = [](int v) { if (PERSIST) asm volatile("" : "+s"(v)); return v; };
-    const int N = opaque_s(a.N), CK = opaque_s(a.CK), K = opaque_s(a.K);
-    const int cks = opaque_s(a.ck_shift), ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
+    const int N = a.N, CK = a.CK, K = a.K;
+    const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
-    const RolloutConsts<T> *kkp = a.k;
-    if (PERSIST) asm volatile("" : "+s"(kkp));
-    const RolloutConsts<T> &kk = *kkp;
-    int tid_ = threadIdx.x;
-    if (PERSIST) asm volatile("" : "+v"(tid_));
-    const int tid = tid_, NT = opaque_s(a.NT);
+    const RolloutConsts<T> &kk = *a.k;
+    const int tid = threadIdx.x, NT = a.NT;
     const int k0 = blockIdx.x * CK;
     // Batched launch (rovmpc_step_batch_device): blockIdx.y = problem.  Every per-problem array is the single-problem
     // array repeated B times; a problem's workgroups, granules, sweeper and record never touch another problem's.
@@ -484,7 +476,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T P0x, P0y, P0z, V0x, V0y, V0z, A0x, A0y, A0z, th0, ga0, thm0, gam0;
     // (closed loop with GPU-side hand-off: the measured row of this step stands in for the state; theta / gamma arrive
     // later, in the waves that need them -- ring_wait / ring_get)
-    const double *sdg = SAMPLE ? a.samp_state : (PERSIST ? a.exo_cur : a.state + (size_t)prob * ROVMPC_STATE_LEN);
+    const double *sdg = SAMPLE ? a.samp_state : (HANDOFF ? a.exo_cur : a.state + (size_t)prob * ROVMPC_STATE_LEN);
     auto sd_at = [&](int i) -> double { return sdg[i]; };
     // Whole-wave call: lane 0 polls the sequence word until the record of this step is out (bounded: on giving up it raises
     // the error word and the wave goes on with whatever the ring holds).
@@ -658,9 +650,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // (compiled-in model: the gamma wave integrates gamma and fills its table meanwhile)
     if (gwave) {
         RV_STAMP_W(8);
-        if (PERSIST && a.from_ring) { ring_wait(a.seq_gamma); ga0 = ring_get(1); gam0 = ring_get(3); }
+        if (HANDOFF && a.from_ring) { ring_wait(a.seq_gamma); ga0 = ring_get(1); gam0 = ring_get(3); }
         gamma_chain();
-        if (PERSIST) {
+        if (HANDOFF) {
             if (a.from_ring || a.plant_feedback) {
                 // sweeper: gamma_1 of this step is every candidate's gamma_1 -- the next step's gamma0, known already
                 if ((int)blockIdx.x == a.sweeper && a.publish && a.plant_feedback) {
@@ -793,7 +785,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         //   A = kty wz,  B = ktx (kt . w),  C = wx - B  (primes: scaled by 1/scale3, B' also shifted).
         for (int i = tid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += NT) {
             const int n = i >> cks, c = i & ckm;
-            RV_PL(sY, 1, n, c) = n == 0 ? (PERSIST ? sG[8 * N + 1] : ga0) : sG[8 * (n - 1) + 5];
+            RV_PL(sY, 1, n, c) = n == 0 ? (HANDOFF ? sG[8 * N + 1] : ga0) : sG[8 * (n - 1) + 5];
             if (VT != ROVMPC_VT_COMPOSE || n == N) continue;
             const T ktx = RV_PL(sA, 0, n, c), kty = RV_PL(sA, 1, n, c);
             const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
@@ -909,7 +901,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T KT = T(0.048152514);
             const T hKT = euler ? kk.h * KT : (kk.h / T(6)) * KT;
             const T K16a = T(3) * i16, K16b = T(-6) * m16 * i16;
-            if (PERSIST && a.wait_theta) {
+            if (HANDOFF && a.wait_theta) {
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); thm0 = ring_get(2); }
             }
@@ -1036,7 +1028,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
         const int nint = 64;
         auto integrate = [&]() {
-            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+            if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
             }
@@ -1162,7 +1154,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // (test_cluster.py:113-129).  State slots 14/15 carry (dtheta, dgamma) at node 0.
         auto integrate_dd = [&]() {
             const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
-            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+            if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
             }
@@ -1293,7 +1285,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         };
         constexpr unsigned VELMASK = 0x21f8u;       // planes 3..8 and 13: velocity, acceleration, angle_proj
         auto integrate_jit = [&]() {
-            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+            if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
             }
@@ -1442,7 +1434,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // VT_COMPOSE no row goes through LDS at all
         auto integrate_dd_jit = [&]() {
             const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
-            if (PERSIST && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
+            if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
             }
@@ -1685,7 +1677,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     RV_STAMP(7);
     if ((int)blockIdx.x != a.sweeper) return;
-    if (PERSIST) {
+    if (HANDOFF) {
         argmin_epilogue<T>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
     } else if (LEAN) {
         argmin_epilogue<T, true>(a, granb, blk_trajb, Ub, resultb, reinterpret_cast<double *>(smem + 4));
@@ -1725,70 +1717,47 @@ rollout_kernel_sampled(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT, false, false, true>(a);
 }
 
-// ---- persistent closed loop --------------------------------------------------------------------------------------
-// BASELINE config 5 on one GPU: ONE launch runs all T steps.  The grid is the single-step grid (every workgroup must be
-// resident: the host checks nblocks against the device's capacity); per step each workgroup does exactly what the
-// single-step kernel does, on candidate batch pools[i % n_pools], and publishes its best as granules tagged with epoch
-// a.epoch + i.  The sweeping workgroup reduces them, writes record i and the state of step i + 1 (write-through) and
-// publishes the step number; the others poll that number before they read the state -- the granule epoch and the step
-// number together are the grid-wide step barrier.  Every wait is bounded by a.handoff_ticks: a workgroup that gives up
-// raises ERR_SWEEP and leaves, the sweeper's bounded sweep follows, and the grid drains.
-struct PersistArgs {
-    long long T;                      // steps
+// ---- closed loop with the state handed over on the GPU ------------------------------------------------------------
+// BASELINE config 5 on one GPU, pipelined form: ONE step per launch, launches alternating between two streams.  Launch
+// g + 1 starts while launch g is still running -- its launch latency, dispatch ramp, control load, phase 2 and gamma chain
+// leave the critical path -- and its workgroups wait on the step number for the state launch g's sweeper publishes
+// (ring / seq_theta / seq_gamma, see RolloutArgs).  Both grids must be resident at once (the host checks it).  Every
+// wait is bounded by a.handoff_ticks: a workgroup that gives up raises ERR_SWEEP and goes on, the sweeper's bounded
+// sweep follows, and the grid drains.  (Round 2 also shipped the loop as ONE launch with the step loop inside the
+// kernel; it was bit-equal and slower than this form -- 21 vs 13 us per step -- and was removed in round 3.)
+struct HandoffArgs {
+    long long T;                      // steps of the whole loop (the last step publishes no state)
     const double *exo;                // [T][16] measured rows (rovmpc_closed_loop_device)
     unsigned long long *seq_theta;    // steps whose (theta | gamma) record the sweepers have published (0 before the loop)
     unsigned long long *seq_gamma;
     double *ring;                     // [4][4], see RolloutArgs
-    unsigned long long *granules2;    // [2][3][nblocks] and
-    double *blk_traj2;                // [2][nblocks][N+1][2]: hand-off buffers by step parity (two steps can be in flight)
-    long long pool_elems;             // K * N * 3
-    int n_pools;
-    long long step_base;              // global index of this launch's first step (pipelined form: T = 1 per launch)
+    unsigned long long *granules2;    // [2][GRAN][nblocks] and
+    double *blk_traj2;                // [2][nblocks][N+1][2]: hand-off buffers by step parity (two steps are in flight)
+    long long step;                   // global index of this launch's step
 };
 
-template <typename T, int MODEL, int VT, bool SINGLE = false>
-RV_DEV void closed_loop_body(const RolloutArgs<T> &a0, const PersistArgs &p) {
-    const int R = 5 + 2 * (a0.N + 1);
-    int pool = (int)(p.step_base % p.n_pools);
-    const long long steps = SINGLE ? 1 : p.T;
-    for (long long i = 0; i < steps; ++i) {
-        const long long g = p.step_base + i;          // global step
-        if (!SINGLE && i > 0) __syncthreads();        // the LDS image of the previous step is free
-        RolloutArgs<T> a = a0;
-        a.U = a0.U + (size_t)pool * p.pool_elems;
-        a.result = a0.result + (size_t)i * R;
-        a.epoch = a0.epoch + (unsigned)i;
-        a.granules = p.granules2 + (size_t)(g & 1) * GRAN * a0.nblocks;
-        a.blk_traj = p.blk_traj2 + (size_t)(g & 1) * a0.nblocks * (a0.N + 1) * 2;
-        a.exo_cur = p.exo + (size_t)g * ROVMPC_STATE_LEN;
-        a.ring = p.ring; a.seq_theta = p.seq_theta; a.seq_gamma = p.seq_gamma;
-        a.step = g;
-        a.from_ring = a0.plant_feedback && g > 0;
-        // the in-launch loop also waits without feedback: a workgroup then runs at most one step ahead of the sweeper
-        a.wait_theta = a.from_ring || (!SINGLE && g > 0);
-        a.publish = g + 1 < p.T;
-        a.plant_next = g + 1 < p.T ? p.exo + (size_t)(g + 1) * ROVMPC_STATE_LEN : nullptr;
-        a.plant_state = const_cast<double *>(a0.state);
-        rollout_body<T, MODEL, VT, true>(a);
-        if (++pool == p.n_pools) pool = 0;
-    }
+// a.U / a.result / a.epoch are already this step's.
+template <typename T, int MODEL, int VT>
+RV_DEV void closed_loop_step_body(const RolloutArgs<T> &a0, const HandoffArgs &p) {
+    const long long g = p.step;
+    RolloutArgs<T> a = a0;
+    a.granules = p.granules2 + (size_t)(g & 1) * GRAN * a0.nblocks;
+    a.blk_traj = p.blk_traj2 + (size_t)(g & 1) * a0.nblocks * (a0.N + 1) * 2;
+    a.exo_cur = p.exo + (size_t)g * ROVMPC_STATE_LEN;
+    a.ring = p.ring; a.seq_theta = p.seq_theta; a.seq_gamma = p.seq_gamma;
+    a.step = g;
+    a.from_ring = a0.plant_feedback && g > 0;
+    a.wait_theta = a.from_ring;
+    a.publish = g + 1 < p.T;
+    a.plant_next = g + 1 < p.T ? p.exo + (size_t)(g + 1) * ROVMPC_STATE_LEN : nullptr;
+    a.plant_state = const_cast<double *>(a0.state);
+    rollout_body<T, MODEL, VT, true>(a);
 }
 
 template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
-closed_loop_kernel(const RolloutArgs<T> a, const PersistArgs p) {
-    closed_loop_body<T, MODEL, VT>(a, p);
-}
-
-// Pipelined form of the same hand-off: ONE step per launch (no loop around the body), launches alternating between two
-// streams.  Launch g + 1 starts while launch g is still running -- its launch latency, dispatch ramp and the previous
-// sweeper's epilogue leave the critical path -- and its workgroups wait on the step number for the state launch g's
-// sweeper publishes.  p.T is the length of the whole loop (the last step publishes no state), a.result / a.epoch are
-// already this step's.
-template <typename T, int MODEL, int VT>
-__global__ void __launch_bounds__(512)
-closed_loop_step_kernel(const RolloutArgs<T> a, const PersistArgs p) {
-    closed_loop_body<T, MODEL, VT, true>(a, p);
+closed_loop_step_kernel(const RolloutArgs<T> a, const HandoffArgs p) {
+    closed_loop_step_body<T, MODEL, VT>(a, p);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

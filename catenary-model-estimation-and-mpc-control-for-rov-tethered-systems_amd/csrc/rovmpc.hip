@@ -32,13 +32,12 @@ struct rovmpc_handle {
     bool has_model = false, builtin = false;
     int model_kind = MODEL_INTERP;   // MODEL_BUILTIN | MODEL_INTERP | MODEL_JIT
     hipFunction_t jit_fn = nullptr;  // MODEL_JIT: kernel of the run-time specialised module
-    hipFunction_t jit_fn_loop = nullptr;   //            its persistent closed-loop entry
     hipFunction_t jit_fn_step = nullptr;   //            its pipelined closed-loop step entry
     hipStream_t pipe_streams[2] = {nullptr, nullptr};     // pipelined closed loop: launches alternate between the two
     bool pipe_placed = false, pipe_stream_owned = false;  // [1] probed against the caller's stream; replaced by one of the handle's own
     std::string pipe_placement;
     hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};
-    // closed loop with GPU-side hand-off (persistent / pipelined): sequence words [2] + state ring [4][4] in one block,
+    // closed loop with GPU-side hand-off (pipelined form): sequence words [2] + state ring [4][4] in one block,
     // and the granule / trajectory hand-off buffers by step parity
     unsigned long long *d_step_seq = nullptr;
     unsigned long long *d_cl_granules = nullptr;
@@ -525,16 +524,16 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
     return st.back().text;
 }
 
-struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_loop = nullptr, fn_step = nullptr; };
+struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_step = nullptr; };
 static std::mutex g_jit_mu;
 static std::map<std::string, JitModule> g_jit_cache;     // key: device ordinal + generated source
 
 // Returns nullptr and fills `why` when hiprtc cannot produce the kernel.
-static hipFunction_t jit_build(int device, const std::string &src, std::string &why, hipFunction_t *fn_loop, hipFunction_t *fn_step) {
+static hipFunction_t jit_build(int device, const std::string &src, std::string &why, hipFunction_t *fn_step) {
     std::lock_guard<std::mutex> lk(g_jit_mu);
     const std::string key = std::to_string(device) + "\n" + src;
     auto it = g_jit_cache.find(key);
-    if (it != g_jit_cache.end()) { *fn_loop = it->second.fn_loop; *fn_step = it->second.fn_step; return it->second.fn; }
+    if (it != g_jit_cache.end()) { *fn_step = it->second.fn_step; return it->second.fn; }
     hiprtcProgram prog = nullptr;
     const char *hdr_src[] = {k_src_rovmpc_h, k_src_device_math_h, k_src_rollout_kernels_h};
     const char *hdr_name[] = {"rovmpc.h", "device_math.h", "rollout_kernels.h"};
@@ -565,10 +564,9 @@ static hipFunction_t jit_build(int device, const std::string &src, std::string &
     if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); return nullptr; }
     e = hipModuleGetFunction(&m.fn, m.mod, "rovmpc_rollout_jit");
     if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); (void)hipModuleUnload(m.mod); return nullptr; }
-    if (hipModuleGetFunction(&m.fn_loop, m.mod, "rovmpc_closed_loop_jit") != hipSuccess) m.fn_loop = nullptr;
     if (hipModuleGetFunction(&m.fn_step, m.mod, "rovmpc_closed_loop_step_jit") != hipSuccess) m.fn_step = nullptr;
     g_jit_cache[key] = m;
-    *fn_loop = m.fn_loop; *fn_step = m.fn_step;
+    *fn_step = m.fn_step;
     return m.fn;
 }
 
@@ -598,10 +596,8 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
          " T; (void)e; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a, p);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a, const rovmpc::PersistArgs p) {\n    rovmpc::closed_loop_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", true>(a, p);\n}\n";
+         "> a, const rovmpc::HandoffArgs p) {\n    rovmpc::closed_loop_step_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a, p);\n}\n";
     if (getenv("ROVMPC_JIT_DUMP")) fprintf(stderr, "[rovmpc] hiprtc translation unit:\n%s\n", s.c_str());
     return s;
 }
@@ -747,12 +743,12 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     }
     h->builtin = same;
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
-    h->jit_fn = nullptr; h->jit_fn_loop = nullptr; h->jit_fn_step = nullptr;
+    h->jit_fn = nullptr; h->jit_fn_step = nullptr;
     h->err.clear();
     if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features <= 18) {
         std::string why;
         const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
-        hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_loop, &h->jit_fn_step);
+        hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_step);
         if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; }
         else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
     }
@@ -2037,7 +2033,7 @@ extern "C" int rovmpc_comm_destroy(rovmpc_handle *h) {
 // ---- closed loop ----------------------------------------------------------------------------------
 
 // Workspace of the GPU-side closed-loop hand-off; fills the pointers of `p` and zeroes the sequence words on `s`.
-static int closed_loop_workspace(rovmpc_handle *h, PersistArgs &p, hipStream_t s) {
+static int closed_loop_workspace(rovmpc_handle *h, HandoffArgs &p, hipStream_t s) {
     const rovmpc_config &c = h->cfg;
     const size_t max_blocks = c.candidates_per_block > 0 ? (size_t)((c.K + c.candidates_per_block - 1) / c.candidates_per_block) : (size_t)c.K;
     if (!h->d_step_seq) {
@@ -2053,75 +2049,9 @@ static int closed_loop_workspace(rovmpc_handle *h, PersistArgs &p, hipStream_t s
     return ROVMPC_OK;
 }
 
-template <typename T, int VT>
-static hipError_t launch_loop(const rovmpc_handle *h, const RolloutArgs<T> &a, const PersistArgs &p, hipStream_t s, int *capacity) {
-    const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
-    auto kern = closed_loop_kernel<T, MODEL_BUILTIN, VT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, a.NT, lds);
-    if (e != hipSuccess) return e;
-    *capacity = per_cu * h->n_cu;
-    if (a.nblocks > *capacity) return hipSuccess;          // the caller refuses: not every workgroup would be resident
-    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(a.NT), lds, s, a, p);
-    return hipGetLastError();
-}
-
-template <typename T>
-static int closed_loop_persistent_t(rovmpc_handle *h, const double *d_exo, int64_t T_steps, double *d_state, const void *d_pools,
-                                    int32_t n_pools, int32_t feedback, double *d_results, hipStream_t s) {
-    const Geo g = launch_geometry(h, 1);
-    // every workgroup must be resident for the whole launch; the occupancy query can be one workgroup per CU high
-    // (MI355X_MICROARCH.md, residency), so ask for a margin: at most one workgroup per CU
-    if (g.nblocks > h->n_cu)
-        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop needs the whole grid resident: %d workgroups > %d compute units "
-                                        "(use rovmpc_closed_loop_device)", g.nblocks, h->n_cu);
-    PersistArgs p;
-    int rcw = closed_loop_workspace(h, p, s);
-    if (rcw) return rcw;
-    // T consecutive epochs tag the granules of the T steps; the tag is never 0 and never repeats within the buffer's life
-    if ((unsigned long long)*h->epoch_ctr + (unsigned long long)T_steps + 1 >= 0xffffffffULL) {
-        HIPCHK(h, hipMemsetAsync(h->d_cl_granules, 0, (size_t)2 * GRAN * g.nblocks * sizeof(unsigned long long), s));
-        *h->epoch_ctr = 0;
-    }
-    hipLaunchKernelGGL(plant_update_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)nullptr);
-    HIPCHK(h, hipGetLastError());
-    RolloutArgs<T> a;
-    h->plant_feedback = feedback ? 1 : 0;
-    fill_args<T>(h, a, d_state, d_pools, nullptr, g, 1);           // takes one epoch: that of step 0
-    h->plant_feedback = 0;
-    *h->epoch_ctr += (unsigned)(T_steps - 1);
-    a.result = d_results; a.k_offset = 0; a.slots = nullptr; a.rank = 0; a.world = 1;
-    a.sweeper = 0;
-    p.T = T_steps; p.exo = d_exo; p.n_pools = n_pools; p.step_base = 0;
-    p.pool_elems = (long long)h->cfg.K * h->cfg.N * 3;
-    const int vt = h->cfg.vt_mode;
-    hipError_t e = hipSuccess;
-    int capacity = 1 << 30;
-    if (h->model_kind == MODEL_JIT) {
-        if (!h->jit_fn_loop) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the run-time specialised module has no persistent entry");
-        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_loop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        struct { RolloutArgs<T> a; PersistArgs p; } both{a, p};
-        size_t asz = sizeof(both);
-        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-        e = hipModuleLaunchKernel(h->jit_fn_loop, a.nblocks, 1, 1, a.NT, 1, 1, (unsigned)lds, s, nullptr, extra);
-    } else if (h->model_kind == MODEL_BUILTIN) {
-        e = vt == 0 ? launch_loop<T, 0>(h, a, p, s, &capacity) : vt == 1 ? launch_loop<T, 1>(h, a, p, s, &capacity) : launch_loop<T, 2>(h, a, p, s, &capacity);
-    } else {
-        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop: compiled-in and hiprtc-specialised models only (the interpreter runs launch per step)");
-    }
-    if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "persistent closed-loop launch failed: %s", hipGetErrorString(e));
-    if (a.nblocks > capacity) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop: %d workgroups exceed the device's resident capacity %d", a.nblocks, capacity);
-    return ROVMPC_OK;
-}
-
 // ---- pipelined closed loop: one step per launch, launches alternating between two streams -----------------------
 template <typename T, int VT>
-static hipError_t launch_step(const rovmpc_handle *h, const RolloutArgs<T> &a, const PersistArgs &p, hipStream_t s, bool probe, int *capacity) {
+static hipError_t launch_step(const rovmpc_handle *h, const RolloutArgs<T> &a, const HandoffArgs &p, hipStream_t s, bool probe, int *capacity) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
     auto kern = closed_loop_step_kernel<T, MODEL_BUILTIN, VT>;
     if (probe) {
@@ -2169,11 +2099,11 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     const int vt = h->cfg.vt_mode;
     const size_t R = rovmpc_result_len(h);
     RolloutArgs<T> a;
-    PersistArgs p;
+    HandoffArgs p;
     int rcw = closed_loop_workspace(h, p, s);
     if (rcw) return rcw;
-    p.T = T_steps; p.exo = d_exo; p.n_pools = n_pools;
-    p.pool_elems = (long long)h->cfg.K * h->cfg.N * 3;
+    p.T = T_steps; p.exo = d_exo;
+    const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * sizeof(T);
     int capacity = 0;
     if (h->model_kind == MODEL_BUILTIN) {
         h->plant_feedback = 0;
@@ -2202,18 +2132,17 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     for (int64_t i = 0; i < T_steps; ++i) {
         hipStream_t st = (i & 1) ? h->pipe_streams[1] : s;
         h->plant_feedback = feedback ? 1 : 0;
-        fill_args<T>(h, a, d_state, (const char *)d_pools + (size_t)(i % n_pools) * p.pool_elems * sizeof(T), nullptr, g, 1);   // one epoch per step
+        fill_args<T>(h, a, d_state, (const char *)d_pools + (size_t)(i % n_pools) * pool_bytes, nullptr, g, 1);   // one epoch per step
         h->plant_feedback = 0;
         a.result = d_results + (size_t)i * R; a.k_offset = 0; a.slots = nullptr; a.rank = 0; a.world = 1;
         a.sweeper = 0;
-        p.step_base = i;
-        PersistArgs pi = p;
-        pi.n_pools = 1;                                          // a.U is already this step's pool
+        p.step = i;
+        const HandoffArgs &pi = p;
         hipError_t e;
         if (h->model_kind == MODEL_JIT) {
             const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            struct { RolloutArgs<T> a; PersistArgs p; } both{a, pi};
+            struct { RolloutArgs<T> a; HandoffArgs p; } both{a, pi};
             size_t asz = sizeof(both);
             void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
             e = hipModuleLaunchKernel(h->jit_fn_step, a.nblocks, 1, 1, a.NT, 1, 1, (unsigned)lds, st, nullptr, extra);
@@ -2243,23 +2172,6 @@ extern "C" int rovmpc_closed_loop_pipelined_device(rovmpc_handle *h, const doubl
     return h->cfg.dtype == ROVMPC_F64
                ? closed_loop_pipelined_t<double>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream)
                : closed_loop_pipelined_t<float>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream);
-}
-
-extern "C" int rovmpc_closed_loop_persistent_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
-                                                    const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
-                                                    void *stream) {
-    if (!h) return ROVMPC_ERR_INVALID;
-    if (T < 1 || T > 1000000000LL || n_pools < 1 || !d_exo || !d_state || !d_pools || !d_results)
-        FAIL(h, ROVMPC_ERR_INVALID, "rovmpc_closed_loop_persistent_device: bad argument");
-    int rc = check_ready(h);
-    if (rc) return rc;
-    if (h->comm) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "persistent closed loop is single-GPU: the sharded loop needs a host-issued collective per step");
-    if (feedback && h->cfg.feature_map == ROVMPC_FEATURES_GEN3)
-        FAIL(h, ROVMPC_ERR_UNSUPPORTED, "closed loop with model feedback carries (theta, gamma) only (see rovmpc_closed_loop_device)");
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    return h->cfg.dtype == ROVMPC_F64
-               ? closed_loop_persistent_t<double>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream)
-               : closed_loop_persistent_t<float>(h, d_exo, T, d_state, d_pools, n_pools, feedback, d_results, (hipStream_t)stream);
 }
 
 extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state, const void *d_pools,

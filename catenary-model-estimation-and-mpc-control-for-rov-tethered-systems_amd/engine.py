@@ -314,16 +314,15 @@ class Engine:
         self._check(self.lib.rovmpc_comm_destroy(self._h))
 
     def closed_loop_device(self, d_exo: int, T: int, d_state: int, d_pools: int, n_pools: int, d_results: int,
-                           k_offset: int = 0, feedback: bool = False, stream: int = 0, persistent: bool = False,
-                           mode: str = ""):
-        """mode: "per_step" (one launch per step, one stream; also the sharded loop), "pipelined" (one launch per step,
-        two streams, GPU-side state hand-off) or "persistent" (one launch for all steps)."""
-        mode = mode or ("persistent" if persistent else "per_step")
-        if mode in ("persistent", "pipelined"):
+                           k_offset: int = 0, feedback: bool = False, stream: int = 0, mode: str = ""):
+        """mode: "per_step" (one launch per step, one stream; also the sharded loop) or "pipelined" (one launch per step,
+        two streams, GPU-side state hand-off; single GPU)."""
+        mode = mode or "per_step"
+        if mode == "pipelined":
             if k_offset:
-                raise ValueError(f"the {mode} loop is single-GPU (k_offset must be 0)")
-            fn = self.lib.rovmpc_closed_loop_persistent_device if mode == "persistent" else self.lib.rovmpc_closed_loop_pipelined_device
-            self._check(fn(self._h, d_exo, T, d_state, d_pools, n_pools, int(feedback), d_results, stream))
+                raise ValueError("the pipelined loop is single-GPU (k_offset must be 0)")
+            self._check(self.lib.rovmpc_closed_loop_pipelined_device(self._h, d_exo, T, d_state, d_pools, n_pools, int(feedback),
+                                                                     d_results, stream))
             return
         if mode != "per_step":
             raise ValueError(f"unknown closed-loop mode {mode!r}")

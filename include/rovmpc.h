@@ -281,16 +281,7 @@ int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, int64_t T, 
                               const void *d_pools, int32_t n_pools, int64_t k_offset,
                               int32_t feedback, double *d_results, void *stream);
 
-/* The same loop (single GPU, no communicator) as ONE persistent launch: every workgroup stays resident for all T steps;
- * per step it does what the single-step kernel does, the sweeping workgroup writes record i and the state of step i + 1
- * and publishes the step number, the others poll it -- no kernel boundary, no dispatch ramp per step.  Records are
- * bit-identical to rovmpc_closed_loop_device's.  ROVMPC_ERR_UNSUPPORTED when the grid cannot be wholly resident
- * (more workgroups than compute units), with a communicator, or for the bytecode interpreter. */
-int rovmpc_closed_loop_persistent_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
-                                         const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
-                                         void *stream);
-
-/* The same loop, pipelined: one step per launch, launches alternating between two internal streams (forked from and joined
+/* The same loop (single GPU, no communicator), pipelined: one step per launch, launches alternating between two internal streams (forked from and joined
  * to `stream`).  Launch i + 1 starts while launch i runs -- its launch latency, dispatch ramp and the previous sweeper's
  * epilogue leave the critical path -- and its workgroups wait, on the GPU, for the state launch i's sweeper publishes.
  * Records are bit-identical to rovmpc_closed_loop_device's.  ROVMPC_ERR_UNSUPPORTED when two grids do not fit the chip

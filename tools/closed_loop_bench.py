@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 5 on one GPU: closed-loop MPC over a synthetic ROV trajectory (Rov_traj_gen case 12, circular), N=20,
-K=4096, real-time factor = simulated time / wall time, for the three loop forms (launch per step / pipelined / persistent),
+K=4096, real-time factor = simulated time / wall time, for the two loop forms (launch per step / pipelined),
 with the model's own (theta, gamma) fed back and on measured rows.
     python tools/closed_loop_bench.py [--steps 10000] [--short 300]
 (--short: a horizon before the fed-back gamma recurrence of the chosen row has drifted off the fast sine path)"""
@@ -25,7 +25,7 @@ eng = rovmpc.Engine(rovmpc.MPCConfig(N=args.N, K=args.K))
 out = {"config": f"closed loop, case {args.case}, N={args.N}, K={args.K}, 1 GPU", "runs": []}
 for feedback in (True, False):
     for T, reps in ((args.steps, 1), (args.short, 20)):
-        for mode in ("per_step", "pipelined", "persistent"):
+        for mode in ("per_step", "pipelined"):
             run_closed_loop(eng, args.case, min(T, 200), feedback=feedback, mode=mode)
             walls = [run_closed_loop(eng, args.case, T, feedback=feedback, mode=mode) for _ in range(reps)]
             rep = min(walls, key=lambda r: r.wall_s)
