@@ -1015,6 +1015,9 @@ extern "C" int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *sta
     const int cur = (int)(h->samp_steps & 1);
     const int warm = warm_start && h->samp_steps > 0;
     const bool fused = h->model_kind == MODEL_BUILTIN && (h->samp_steps == 0 || h->last_fused) && !h->timing;
+    // a fused step keeps its winner's sequence in d_best only (the candidate tensor never exists): when the handle leaves the
+    // fused path -- rovmpc_timing_enable, or rovmpc_set_model with another model -- the next step's warm start reads it there
+    const bool prev_fused = h->samp_steps > 0 && h->last_fused;
     h->last_seed = seed; h->last_step = step; h->last_warm = warm; h->last_fused = fused;
     for (int i = 0; i < 3; ++i) { h->last_mean[i] = mean3[i]; h->last_std[i] = std3[i]; }
     unsigned long long seq = h->samp_steps + 1;
@@ -1029,7 +1032,8 @@ extern "C" int rovmpc_mpc_step_sampled(rovmpc_handle *h, const rovmpc_state *sta
         ++h->samp_steps;
         if (rc) return rc;
     } else {
-    if ((rc = launch_sampler(h, state, seed, step, mean3, std3, warm, h->d_Us[cur], h->d_Us[cur ^ 1], h->stream))) return rc;
+    const double *warm_seq = (warm && prev_fused) ? h->d_best + (size_t)(cur ^ 1) * h->cfg.N * 3 : nullptr;
+    if ((rc = launch_sampler(h, state, seed, step, mean3, std3, warm, h->d_Us[cur], h->d_Us[cur ^ 1], h->stream, warm_seq))) return rc;
     seq = ++h->samp_steps;
     h->arg_result_host = h->d_record_host; h->arg_done_flag = h->d_done; h->arg_done_seq = seq;
     rc = enqueue_step(h, h->d_state, h->d_Us[cur], nullptr, h->d_result, 0, nullptr, 0, 1, h->stream);

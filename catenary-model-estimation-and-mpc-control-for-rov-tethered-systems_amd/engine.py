@@ -144,6 +144,7 @@ class Engine:
                 raise TypeError(f"unknown config field {k!r}")
             setattr(self.cfg, k, v)
         self._h = C.c_void_p()
+        self.has_comm = False          # rovmpc_comm_init has been called: steps of the closed-loop driver are the sharded ones
         c = self.cfg.to_c()
         rc = self.lib.rovmpc_create(C.byref(c), C.byref(self._h))
         if rc != 0:
@@ -275,6 +276,7 @@ class Engine:
         if len(unique_id) != 128:
             raise ValueError("unique_id must be 128 bytes")
         self._check(self.lib.rovmpc_comm_init(self._h, C.create_string_buffer(unique_id, 128), rank, world))
+        self.has_comm = True
 
     def step_device_allreduce(self, d_state: int, d_U: int, k_offset: int, d_result: int, stream: int = 0):
         self._check(self.lib.rovmpc_step_device_allreduce(self._h, d_state, d_U, k_offset, d_result, stream))
@@ -311,6 +313,7 @@ class Engine:
         return p.value
 
     def comm_destroy(self):
+        self.has_comm = False
         self._check(self.lib.rovmpc_comm_destroy(self._h))
 
     def closed_loop_device(self, d_exo: int, T: int, d_state: int, d_pools: int, n_pools: int, d_results: int,

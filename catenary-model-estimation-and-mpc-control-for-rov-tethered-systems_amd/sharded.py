@@ -131,6 +131,11 @@ class ShardedMPC:
         self._enqueue(d_state, d_U, i, cur, self.comm_stream)
         return self.results[i]
 
+    def join(self):
+        """The current stream waits (on the GPU, no host block) for every enqueued step's global record."""
+        if not self.host_staged:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
     def synchronize(self):
         torch.cuda.current_stream().wait_stream(self.comm_stream)
         torch.cuda.current_stream().synchronize()
@@ -200,6 +205,10 @@ class NativeShardedMPC:
         self.engine.step_device_allreduce(d_state.data_ptr(), d_U.data_ptr(), self.k_offset,
                                           self.results[i].data_ptr(), torch.cuda.current_stream().cuda_stream)
         return self.results[i]
+
+    def join(self):
+        """The current stream waits (on the GPU, no host block) for every enqueued step's global record."""
+        self.engine.comm_join(torch.cuda.current_stream().cuda_stream)
 
     def synchronize(self):
         """Blocks until every enqueued step's global record is final; raises ``RovmpcError`` when a GPU-side hand-off

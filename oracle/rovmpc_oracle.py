@@ -979,6 +979,39 @@ def mpc_step(cfg, model, state, U, Rtab=None, flavour="vec"):
     return np.asarray(U)[k, 0, :].copy(), traj[k].copy(), float(J[k]), k
 
 
+def closed_loop(cfg, model, rows, pools, feedback, n_steps=None, Rtab=None, k_offset=0):
+    """BASELINE config 5: an MPC step per sample of a trajectory table (build-defined -- the reference has no controller;
+    its per-frame loop over recorded rows is catenary_from_data.py:40-50, the table comes from Rov_traj_gen.py:7-116).
+
+    Plant rule = rovmpc_closed_loop_device / plant_update_kernel: step i starts from the measured row ``rows[i]`` (16
+    doubles in rovmpc_state order: P0, P1, V1, A1, theta, gamma, theta_prev, gamma_prev).  With ``feedback``, from the second
+    step on only the exogenous slots 0..11 come from the row; (theta, gamma) = the first predicted node of step i - 1's
+    winner, and (theta_prev, gamma_prev) = the (theta, gamma) step i - 1 started from (np.roll, simply.py:35-38).  Step i
+    rolls out candidate batch ``pools[i % len(pools)]`` (``rollout_vec``) and takes np.argmin (lowest index on ties).
+
+    Returns dict(cost (T,), index (T,) + k_offset, u (T, 3), theta_gamma (T + 1, 2), states (T, 16), traj (T, N + 1, 2))."""
+    rows = np.asarray(rows, dtype=np.float64)
+    T = len(rows) if n_steps is None else int(n_steps)
+    cost = np.empty(T); index = np.empty(T, dtype=np.int64); u = np.empty((T, 3))
+    states = np.empty((T, 16)); trajs = np.empty((T, cfg.N + 1, 2))
+    st = rows[0].copy()
+    for i in range(T):
+        if feedback and i > 0:
+            th, ga = st[12], st[13]
+            st = st.copy()
+            st[0:12] = rows[i][0:12]
+            st[14], st[15] = th, ga
+            st[12], st[13] = trajs[i - 1, 1]
+        else:
+            st = rows[i].copy()
+        U = np.asarray(pools[i % len(pools)], dtype=np.float64)
+        J, traj, _ = rollout_vec(cfg, model, MPCState.from_array(st), U, Rtab)
+        k = int(np.argmin(J))
+        cost[i] = J[k]; index[i] = k + k_offset; u[i] = U[k, 0]; states[i] = st; trajs[i] = traj[k]
+    tg = np.vstack([trajs[0, 0], trajs[:, 1]])
+    return {"cost": cost, "index": index, "u": u, "theta_gamma": tg, "states": states, "traj": trajs}
+
+
 # --------------------------------------------------------------------------------------
 # A9 -- ROV trajectory generator (Rov_traj_gen.py:7-116)
 # --------------------------------------------------------------------------------------
