@@ -183,6 +183,8 @@ RV_DEV double m_sqrt(double x) { return ::sqrt(x); }
 RV_DEV float  m_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32: 1 ulp, no fix-up sequence
 RV_DEV double m_pow(double x, double y) { return ::pow(x, y); }
 RV_DEV float  m_pow(float x, float y)  { return ::powf(x, y); }
+RV_DEV double m_fma(double a, double b, double c) { return ::fma(a, b, c); }
+RV_DEV float  m_fma(float a, float b, float c)  { return ::fmaf(a, b, c); }
 RV_DEV double m_abs(double x) { return ::fabs(x); }
 RV_DEV float  m_abs(float x)  { return ::fabsf(x); }
 RV_DEV double m_min(double a, double b) { return ::fmin(a, b); }
@@ -267,13 +269,13 @@ template <typename T> RV_DEV V3<T> rodrigues_flat(V3<T> v, T kx, T ky, T s, T c)
 // theta axis = normalize(xy_projection(rel)) x z (fallbacks [1,0,0] / [0,1,0] below 1e-9),
 // gamma axis = rel / |rel| (no epsilon in the reference: |rel| = 0 yields NaN there too).
 template <typename T> RV_DEV void theta_gamma_axes(V3<T> rel, V3<T> &th_axis, V3<T> &ga_axis) {
-    T nxy = m_sqrt(rel.x * rel.x + rel.y * rel.y);
+    T nxy = m_sqrtq(rel.x * rel.x + rel.y * rel.y);
     T ex, ey;
     if (nxy < T(1e-9)) { ex = T(1); ey = T(0); } else { T inv = m_div(T(1), nxy); ex = rel.x * inv; ey = rel.y * inv; }
     // cross([ex,ey,0],[0,0,1]) = [ey,-ex,0]; its norm is 1 (unit xy) so the second fallback
     // of main_fun.py:86-89 can only trigger for a NaN input.
     th_axis = {ey, -ex, T(0)};
-    T inv = m_div(T(1), m_sqrt(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z));
+    T inv = m_div(T(1), m_sqrtq(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z));
     ga_axis = {rel.x * inv, rel.y * inv, rel.z * inv};
 }
 
@@ -301,9 +303,24 @@ template <typename T> RV_DEV T sinh_pos(T x) {
     return T(0.5) * (e - T(1) / e);
 }
 
-// Result of the catenary-parameter solve: C (NaN if none), u = l C / 2 and r = sqrt(L^2-dH^2)/l,
-// so that sinh(u) = r u at the root (reused by the tension rule and the shape samples).
-template <typename T> struct CatRoot { T C, u, r; };
+// Result of the catenary-parameter solve: C (NaN if none), u = l C / 2, r = sqrt(L^2-dH^2)/l -- so that sinh(u) = r u at
+// the root (reused by the tension rule and the shape samples) -- and e = exp(u) (carried out of the iteration: the shape
+// samples and the warm start of a nearby system need it, and the iteration has it for a handful of instructions).
+template <typename T> struct CatRoot { T C, u, r, e; };
+
+// e^d for |d| < 2^-5 (fp64: Taylor to d^7, truncation < 2e-17 relative; fp32: to d^4, < 3e-10): how exp(u) is carried from
+// one Halley iterate to the next, u' = u + d, instead of being evaluated again.
+RV_DEV double exp_increment(double d) {
+    double p = 1.0 / 5040;
+    p = ::fma(p, d, 1.0 / 720); p = ::fma(p, d, 1.0 / 120); p = ::fma(p, d, 1.0 / 24);
+    p = ::fma(p, d, 1.0 / 6); p = ::fma(p, d, 0.5); p = ::fma(p, d, 1.0);
+    return ::fma(p, d, 1.0);
+}
+RV_DEV float exp_increment(float d) {
+    float p = ::fmaf(d, 1.0f / 24, 1.0f / 6);
+    p = ::fmaf(p, d, 0.5f); p = ::fmaf(p, d, 1.0f);
+    return ::fmaf(p, d, 1.0f);
+}
 
 // solve_catenary (main_fun.py:418-431): the root C* of f(C) = C^2 (L^2 - dH^2) - 4 sinh^2(l C / 2)
 // that scipy brentq returns on [c_lo, c_hi], NaN when brentq raises.  brentq raises exactly
@@ -321,92 +338,78 @@ template <typename T> struct CatRoot { T C, u, r; };
 //    h' = (cosh u - 1) - (r - 1) with r - 1 = (L2 - l^2) / (l (sqrt(L2) + l));
 //  * three iterations are unrolled (cubic convergence: the last step is < 2e-8 relative for
 //    every r <= 8); systems whose last step was still > 1e-6 keep iterating, so the result
-//    never depends on the unroll count.
-// NS independent systems advance in lockstep: the per-node rollout needs two solves (cable
-// tension on the straight geometry, shape on the theta-rotated end point) and interleaving
-// them doubles the instruction-level parallelism of an otherwise latency-bound chain.
-// Warm start (u_warm, ch_warm = cosh u_warm): the root of a NEARBY system -- the rollout solves the same cable at
+//    never depends on the unroll count;
+//  * exp(u) is evaluated once: an iterate that moved by |d| < 2^-5 takes e^u e^d with the short polynomial of d (round 3:
+//    an exp is ~30 instructions, the increment 8; the rollout's per-node geometry ran seven exps, now two).
+// Warm start (WARM; u_warm, e_warm = exp(u_warm)): the root of a NEARBY system -- the rollout solves the same cable at
 // the same node twice, for the end point and for the end point turned by theta about a horizontal axis, a few
 // parts in a thousand apart -- accepted when h'(u_warm) = cosh u_warm - r > 0 (Newton-type steps from there land
 // above the root and descend).  Two iterations then reach 1e-14 (measured over the benchmark's geometry); a system
 // without a usable warm start takes the series bound and the tail loop runs the extra iterations it needs.
-template <typename T, int NS>
-RV_DEV void solve_catenary_roots(const T (&l)[NS], const T (&dH)[NS], T L, T c_lo, T c_hi, CatRoot<T> (&out)[NS],
-                                 const T *u_warm = nullptr, const T *ch_warm = nullptr) {
-    T u[NS], r[NS], rm1[NS];
-    bool ok[NS], moving[NS];          // moving: the last step changed u by more than 1e-6 relative
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const T L2 = L * L - dH[s] * dH[s];
-        const T sq = m_sqrtq(L2);
-        r[s] = m_div(sq, l[s]);
-        rm1[s] = m_div(L2 - l[s] * l[s], l[s] * (sq + l[s]));
-        const bool warm = u_warm && u_warm[s] > T(0) && ch_warm[s] > r[s] && rm1[s] > T(0) && m_finite(r[s]);
-        if (warm) {
-            u[s] = u_warm[s];
-            ok[s] = true;
-        } else {
-            u[s] = m_sqrt(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrt(T(1.0 / 36.0) + rm1[s] * T(1.0 / 30.0))), T(0)));
-            ok[s] = rm1[s] > T(0) && m_finite(r[s]) && m_finite(u[s]) && u[s] > T(0);
-            if (!ok[s]) { u[s] = T(1); r[s] = T(2); rm1[s] = T(1); }
-            if (r[s] > T(8)) {
-                T ul = m_log(T(2) * r[s] * u[s]);
-                ul = m_log(T(2) * r[s] * ul) + T(0.05);
-                if (ul > T(0) && ul < u[s]) u[s] = ul;
-            }
-        }
-        moving[s] = true;
+template <typename T, bool WARM>
+RV_DEV CatRoot<T> solve_catenary_root_impl(T l, T dH, T L, T c_lo, T c_hi, T u_warm, T e_warm) {
+    const T L2 = L * L - dH * dH;
+    const T sq = m_sqrtq(L2);
+    T r = m_div(sq, l);
+    T rm1 = m_div(L2 - l * l, l * (sq + l));
+    T u, e = T(-1);                  // e = exp(u) of the current iterate, or < 0: not known
+    bool ok;
+    bool warm = false;
+    if (WARM) {
+        const T chw = T(0.5) * (e_warm + fast_rcp(e_warm));          // (e_warm > 0 whenever u_warm > 0)
+        warm = u_warm > T(0) && chw > r && rm1 > T(0) && m_finite(r);
     }
-    auto halley = [&](int s) {
+    if (warm) {
+        u = u_warm; e = e_warm;
+        ok = true;
+    } else {
+        u = m_sqrtq(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrtq(T(1.0 / 36.0) + rm1 * T(1.0 / 30.0))), T(0)));
+        ok = rm1 > T(0) && m_finite(r) && m_finite(u) && u > T(0);
+        if (!ok) { u = T(1); r = T(2); rm1 = T(1); }
+        if (r > T(8)) {
+            T ul = m_log(T(2) * r * u);
+            ul = m_log(T(2) * r * ul) + T(0.05);
+            if (ul > T(0) && ul < u) u = ul;
+        }
+    }
+    bool moving = true;               // the last step changed u by more than 1e-6 relative
+    auto halley = [&]() {
         T h, hp, sh;
-        if (u[s] < T(0.5)) {
-            const T u2 = u[s] * u[s];
+        if (u < T(0.5)) {
+            const T u2 = u * u;
             const T S = sinhc_m1_small(u2);
-            sh = u[s] * (T(1) + S);
-            h = u[s] * (S - rm1[s]);
-            hp = cosh_m1_small(u2) - rm1[s];
+            sh = u * (T(1) + S);
+            h = u * (S - rm1);
+            hp = cosh_m1_small(u2) - rm1;
+            e = T(-1);
         } else {
-            const T e = m_exp(u[s]), ei = fast_rcp(e);            // 1 <= e < e^(c_hi L / 2): finite, positive
+            if (e < T(0)) e = m_exp(u);                              // 1 <= e < e^(c_hi L / 2): finite, positive
+            const T ei = fast_rcp(e);
             sh = T(0.5) * (e - ei);
-            h = sh - r[s] * u[s];
-            hp = T(0.5) * (e + ei) - r[s];
+            h = sh - r * u;
+            hp = T(0.5) * (e + ei) - r;
         }
-        T un = u[s] - (T(2) * h * hp) * fast_rcp(T(2) * hp * hp - h * sh);   // a zero or infinite denominator gives NaN: caught below
-        if (!(m_finite(un) && un > T(0))) un = u[s];
-        moving[s] = m_abs(un - u[s]) > T(1e-6) * un;
-        u[s] = un;
+        T un = u - (T(2) * h * hp) * fast_rcp(T(2) * hp * hp - h * sh);   // a zero or infinite denominator gives NaN: caught below
+        if (!(m_finite(un) && un > T(0))) un = u;
+        const T d = un - u;
+        moving = m_abs(d) > T(1e-6) * un;
+        e = (e > T(0) && m_abs(d) < T(0.03125)) ? e * exp_increment(d) : T(-1);
+        u = un;
     };
-    const int fixed = u_warm ? 2 : 3;
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        if (it < fixed) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) halley(s);
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-        for (int it = 0; it < 40 && moving[s] && ok[s]; ++it) halley(s);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const T C = m_div(T(2) * u[s], l[s]);
-        const bool in = ok[s] && C >= c_lo && C <= c_hi;
-        out[s].u = u[s]; out[s].r = r[s];
-        out[s].C = in ? C : m_nan<T>();
-    }
+    halley(); halley();
+    if (!WARM) halley();
+    for (int it = 0; it < 40 && moving && ok; ++it) halley();
+    if (e < T(0)) e = m_exp(u);                                      // (near-taut roots, u < 0.5: the series path carries no exp)
+    const T C = m_div(T(2) * u, l);
+    const bool in = ok && C >= c_lo && C <= c_hi;
+    return {in ? C : m_nan<T>(), u, r, e};
 }
 
 template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_lo, T c_hi) {
-    const T la[1] = {l}, da[1] = {dH};
-    CatRoot<T> o[1];
-    solve_catenary_roots<T, 1>(la, da, L, c_lo, c_hi, o);
-    return o[0];
+    return solve_catenary_root_impl<T, false>(l, dH, L, c_lo, c_hi, T(0), T(1));
 }
-template <typename T> RV_DEV CatRoot<T> solve_catenary_root_warm(T l, T dH, T L, T c_lo, T c_hi, T u_warm, T ch_warm) {
-    const T la[1] = {l}, da[1] = {dH}, uw[1] = {u_warm}, cw[1] = {ch_warm};
-    CatRoot<T> o[1];
-    solve_catenary_roots<T, 1>(la, da, L, c_lo, c_hi, o, uw, cw);
-    return o[0];
+template <typename T> RV_DEV CatRoot<T> solve_catenary_root_warm(T l, T dH, T L, T c_lo, T c_hi, T u_warm, T e_warm) {
+    return solve_catenary_root_impl<T, true>(l, dH, L, c_lo, c_hi, u_warm, e_warm);
 }
 
 template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) {
@@ -430,11 +433,9 @@ template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
 // R_gamma -- one 3-vector per node instead of two Rodrigues per point.
 template <typename T> struct AugShape { V3<T> Bp, m; T lp, dHp; };
 
-template <typename T, typename TrigT>
-RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T theta, T gamma, T up, const TrigT &trig) {
-    T st, ct, sg, cg;
-    trig.sincos(theta, &st, &ct);
-    trig.sincos(gamma, &sg, &cg);
+// (st, ct) = sincos(theta), (sg, cg) = sincos(gamma)
+template <typename T>
+RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T st, T ct, T sg, T cg, T up) {
     AugShape<T> a;
     a.Bp = rodrigues_flat(rel, kt.x, kt.y, st, ct);                  // main_fun.py:92 (kt.z == 0 by construction, :75-89)
     const T omc = T(1) - cg;
@@ -447,31 +448,35 @@ RV_DEV AugShape<T> augmented_prepare(V3<T> rel, V3<T> kt, V3<T> kg, T theta, T g
 
 // The cosh samples are equally spaced in their argument a + j d, a = atanh(dH'/L) - u',
 // d = 2u'/(M-1), so e^{a+jd} and e^{-(a+jd)} advance by one multiplication each
-// (e^a = sqrt((L+dH')/(L-dH')) e^{-u'}): two exp per node instead of M cosh + atanh.
+// (e^a = sqrt((L+dH')/(L-dH')) e^{-u'}, e^{u'} comes with the root): one exp per node instead of M cosh + atanh.
+// Sample j (reference: t_j = j / (M - 1), s_j = (cosh(C'(l' t_j - x0)) - cosh(C' x0)) / C', z_j = up (t_j hx + mz C' s_j)) is
+//   z_j = j a + b (E_j + 1/E_j) + c0,   a = up hx / (M - 1),  b = m.z / (2 C'),  c0 = -b (E_0 + 1/E_0):
+// two products, two sums, one FMA and the minimum per sample (round 3; the literal form took twelve instructions).  np.min
+// propagates NaN: a NaN in any sample is a NaN in the last one (E_j, 1/E_j and the running j a keep it), except that
+// 0 * inf at j = 0 needs hx and mz themselves finite -- both are checked once behind the loop instead of once per sample.
+// inv_Mm1 = 1 / (M - 1), from the host.
 template <typename T>
-RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T up) {
+RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T inv_Mm1, T up) {
     T best;
     if (c.C == c.C) {
         // a valid root means L^2 - dH'^2 > l'^2 > 0: every quantity inverted below is finite and positive
-        const T eu = m_exp(c.u);
-        T E = m_sqrtq(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(eu);    // e^{a}
+        T E = m_sqrtq(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(c.e);    // e^{a}
         T Ei = fast_rcp(E);
-        const T invden = m_div(T(1), T(M - 1));
-        const T Ed = m_exp(T(2) * c.u * invden), Edi = fast_rcp(Ed);
-        const T ch0 = T(0.5) * (E + Ei);                 // cosh(C' x0)
-        const T hx = a.m.x * a.Bp.x + a.m.y * a.Bp.y;    // horizontal part of m . q_j is t_j * hx
-        const T mz = m_div(a.m.z * up, c.C);
-        best = m_inf<T>();
-        bool bad = false;                                // np.min propagates NaN
-        for (int j = 0; j < M; ++j) {
-            const T t = T(j) * invden;
-            const T s = T(0.5) * (E + Ei) - ch0;         // C' s_j
-            const T z = up * (t * hx + mz * s);
-            bad |= z != z;
-            best = m_min(best, z);                       // minNum: a NaN operand is dropped, `bad` remembers it
+        const T Ed = m_exp(T(2) * c.u * inv_Mm1), Edi = fast_rcp(Ed);
+        const T hx = up * (a.m.x * a.Bp.x + a.m.y * a.Bp.y);   // horizontal part of m . q_j is t_j * hx (up = +-1 folded in:
+        const T mz = m_div(a.m.z, c.C);                        //  the reference's mz carries up as well, up * up = 1)
+        const T sa = hx * inv_Mm1, sb = T(0.5) * mz;
+        T lin = -(sb * (E + Ei));                        // c0; + a per sample
+        T z = T(0);                                      // sample 0 is the anchor itself
+        best = T(0);
+        for (int j = 1; j < M; ++j) {
             E *= Ed; Ei *= Edi;
+            lin += sa;
+            z = m_fma(sb, E + Ei, lin);
+            best = m_min(best, z);                       // minNum: a NaN operand is dropped; see above
         }
-        if (bad) best = m_nan<T>();
+        const T chk = z + ((hx - hx) + (mz - mz));       // NaN iff a sample was (or hx / mz is not finite)
+        if (chk != chk) best = m_nan<T>();
     } else {
         // catenary_fn(...)[3] is None -> straight segment [A, B'] (main_fun.py:67-69)
         const T zb = up * dot3(a.m, a.Bp);

@@ -57,7 +57,7 @@ constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + un
 template <bool B> struct BoolC { static constexpr bool value = B; };   // compile-time flag for generic lambdas
 
 template <typename T> struct RolloutConsts {
-    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up, vs;
+    T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up, vs, inv_Mm1;       // inv_Mm1 = 1 / (n_shape_pts - 1)
     T w_theta, w_gamma, w_u, w_T, w_taut, rhoL, w_floor, z_floor, theta_ref, gamma_ref;
     T Uref[3];
     T mean[18], inv_scale[18];
@@ -425,7 +425,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     e += planes * (size_t)(N + 1) * CK;              // node planes
     e += (size_t)CK * ((3 * N) | 1);                 // U chunk, odd row stride (bank spread)
     e += (size_t)CK * N;                             // node costs
-    e += (size_t)2 * CK * N;                         // warm start of the second catenary solve of a node (u, cosh u)
+    e += (size_t)2 * CK * N;                         // warm start of the second catenary solve of a node (u, exp u)
     if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
     if (model == MODEL_BUILTIN) e += (size_t)8 * (N + 1);                    // candidate-invariant gamma table
     return e;
@@ -466,7 +466,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     T *sA = sX + NX * (N + 1) * CK;                  // NA planes (rotation axes [, unit_rel])
     T *sU = sA + NA * (N + 1) * CK;                  // [c][n][3]
     T *sC = sU + CK * US;                            // [n][c] node costs
-    T *sW = sC + CK * N;                             // [2][n][c]: root of phase 4a's solve and its cosh (warm start of 4b's)
+    T *sW = sC + CK * N;                             // [2][n][c]: root of phase 4a's solve and its exp (warm start of 4b's)
     T *sF = sW + 2 * CK * N;                         // interpreter: 18 feature rows + stack
     T *sG = sW + 2 * CK * N;                             // compiled-in model: gamma table [N + 1][8]
     int *s_prog = s_best_c + 2;                      // [1]: theta steps finished (early phase-4b batch)
@@ -548,14 +548,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // item 3n + r -- r = 0 sincos(gamma_n), 1 sin(x17 at t_n+1), 2 sin(x17 at the midpoint); the last
         // item is sin(x17 at t_0).  One wave's DS operations complete in order, so the reads see the
         // chain's stores.
-        for (int i = lane; i <= 3 * nsteps; i += 64) {
-            const int n = i == 3 * nsteps ? 0 : i / 3, r = i == 3 * nsteps ? 3 : i - 3 * n;
+        // (and one more: sincos(gamma_N), which only the geometry of the last node reads -- row N, slots 2 / 3)
+        for (int i = lane; i <= 3 * nsteps + (nsteps > 0 ? 1 : 0); i += 64) {
+            const bool last = i == 3 * nsteps + 1;
+            const int n = last ? nsteps : (i == 3 * nsteps ? 0 : i / 3), r = last ? 0 : (i == 3 * nsteps ? 3 : i - 3 * n);
             const T g_n = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
             const T g_m = n == 0 ? gam0 : (n == 1 ? ga0 : sG[8 * (n - 2) + 5]);
             const T s17a = (g_m - m17) * i17, s17b = (g_n - m17) * i17;
             T sv, cv;
             trig.sincos(r == 0 ? g_n : (r == 1 ? s17b : (r == 2 ? (s17a + s17b) / T(2) : s17a)), &sv, &cv);
-            if (r == 0) { sG[8 * n] = sv; sG[8 * n + 1] = cv; }
+            if (last) { sG[8 * n + 2] = sv; sG[8 * n + 3] = cv; }
+            else if (r == 0) { sG[8 * n] = sv; sG[8 * n + 1] = cv; }
             else if (r == 3) sG[8 * N] = sv;
             else sG[8 * n + 2 + r] = sv;
         }
@@ -822,11 +825,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const T d = m_sqrtq(rx * rx + ry * ry + rz * rz);
             const CatRoot<T> cr = solve_catenary_root<T>(l, dH, kk.L, kk.c_lo, kk.c_hi);   // :303
             const T Tn = cable_tension<T>(l, cr, kk.w_per_len);                   // :304-305
-            {
-                const T shu = cr.r * cr.u;                                        // sinh u at the root
-                sW[n * CK + c] = (cr.C == cr.C) ? cr.u : T(-1);
-                sW[(N + n) * CK + c] = m_sqrtq(T(1) + shu * shu);
-            }
+            sW[n * CK + c] = (cr.C == cr.C) ? cr.u : T(-1);                      // warm start of phase 4b's solve of this node:
+            sW[(N + n) * CK + c] = cr.e;                                          // the root and its exp
             const T e0 = u[0] - kk.Uref[0], e1 = u[1] - kk.Uref[1], e2 = u[2] - kk.Uref[2];
             const T taut = m_max(T(0), d - kk.rhoL);
             sC[n * CK + c] = kk.w_u * (e0 * e0 + e1 * e1 + e2 * e2) + kk.w_T * Tn + kk.w_taut * (taut * taut);
@@ -844,9 +844,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T th = RV_PL(sY, 0, n + 1, c), ga = RV_PL(sY, 1, n + 1, c);
         const V3<T> kt = {RV_PL(sA, 0, n + 1, c), RV_PL(sA, 1, n + 1, c), T(0)};
         const V3<T> kg = {RV_PL(sA, 2, n + 1, c), RV_PL(sA, 3, n + 1, c), RV_PL(sA, 4, n + 1, c)};
-        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, kt, kg, th, ga, kk.up, trig4);
+        T st, ct, sg, cg;
+        trig4.sincos(th, &st, &ct);
+        if (MODEL == MODEL_BUILTIN) {
+            // sincos(gamma_{n+1}) is candidate-invariant: the gamma wave left it in its table (node N: row N, slots 2 / 3)
+            const int gi = n + 1 < N ? 8 * (n + 1) : 8 * N + 2;
+            sg = sG[gi]; cg = sG[gi + 1];
+        } else {
+            trig4.sincos(ga, &sg, &cg);
+        }
+        const AugShape<T> sh = augmented_prepare<T>({rx, ry, rz}, kt, kg, st, ct, sg, cg, kk.up);
         const CatRoot<T> cr = solve_catenary_root_warm<T>(sh.lp, sh.dHp, kk.L, kk.c_lo, kk.c_hi, sW[n * CK + c], sW[(N + n) * CK + c]);   // Catenary(A, B')
-        const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.up);
+        const T zl = P0z + augmented_finish<T>(sh, cr, kk.L, a.M, kk.inv_Mm1, kk.up);
         const T eth = th - kk.theta_ref, ega = ga - kk.gamma_ref;
         const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
         sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);

@@ -422,6 +422,7 @@ template <typename T> static void fill_consts(const rovmpc_handle *h, RolloutCon
     k.h = (T)c.dt; k.vs_h = (T)(c.v_scale * c.dt); k.vs = (T)c.v_scale; k.inv_h = (T)(1.0 / c.dt); k.L = (T)c.L;
     k.w_per_len = (T)(c.cable_wet_weight / c.L); k.c_lo = (T)c.c_lo; k.c_hi = (T)c.c_hi;
     k.up = c.frame == ROVMPC_ENU ? (T)1 : (T)-1;
+    k.inv_Mm1 = (T)(1.0 / (double)(c.n_shape_pts - 1));
     k.w_theta = (T)c.w_theta; k.w_gamma = (T)c.w_gamma; k.w_u = (T)c.w_u; k.w_T = (T)c.w_T;
     k.w_taut = (T)c.w_taut; k.rhoL = (T)(c.rho_taut * c.L); k.w_floor = (T)c.w_floor; k.z_floor = (T)c.z_floor;
     k.theta_ref = (T)c.theta_ref; k.gamma_ref = (T)c.gamma_ref;
@@ -814,7 +815,8 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, in
     // the plain single-problem step of the compiled-in model takes the lean instantiation (see rollout_body)
     const bool lean = MODEL == MODEL_BUILTIN && B == 1 && !a.slots && !a.flag_consumed && !a.flag_rolled && !a.result_host &&
                       !a.done_flag && !a.plant_next;
-    auto kern = lean ? rollout_kernel_lean<T, MODEL, VT> : rollout_kernel<T, MODEL, VT>;
+    auto kern = rollout_kernel<T, MODEL, VT>;
+    if constexpr (MODEL == MODEL_BUILTIN) { if (lean) kern = rollout_kernel_lean<T, MODEL, VT>; }     // (no lean instance of the interpreter kernel)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -28,12 +28,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ck", type=int, default=0)
     ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--debug-flags", type=int, default=0, help="phase ablation (diagnostics; results invalid): 1 no integration, 2 no geometry, 4 no phase 2")
     ap.add_argument("--check", action="store_true", help="compare problems 0 and B-1 with their single launches, bit for bit")
     args = ap.parse_args()
     import torch
     import rovmpc
     dev = torch.device("cuda", 0)
-    cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, candidates_per_block=args.ck, threads_per_block=args.nt)
+    cfg = rovmpc.MPCConfig(N=args.N, K=args.K, dtype=args.dtype, candidates_per_block=args.ck, threads_per_block=args.nt,
+                           debug_flags=args.debug_flags)
     B, N, K = args.B, args.N, args.K
     with rovmpc.Engine(cfg) as eng:
         R = eng.result_len
