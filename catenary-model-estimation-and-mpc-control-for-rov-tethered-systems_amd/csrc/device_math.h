@@ -17,6 +17,10 @@ namespace rovmpc {
 
 #define RV_DEV __device__ __forceinline__
 
+template <bool B> struct BoolC { static constexpr bool value = B; };   // compile-time flag for generic lambdas
+template <bool B, typename X, typename Y> struct RvCond { typedef X type; };        // (std::conditional: hiprtc has no <type_traits>)
+template <typename X, typename Y> struct RvCond<false, X, Y> { typedef Y type; };
+
 // fp64 sin/cos.  The device library's double-precision sin/cos carry their argument
 // reduction and polynomial in double-double arithmetic (~120 VALU instructions per call, a
 // Payne-Hanek branch on top); the rollout's sequential phase issues up to ten of them per
@@ -191,6 +195,10 @@ RV_DEV double m_min(double a, double b) { return ::fmin(a, b); }
 RV_DEV float  m_min(float a, float b)  { return ::fminf(a, b); }
 RV_DEV double m_max(double a, double b) { return ::fmax(a, b); }
 RV_DEV float  m_max(float a, float b)  { return ::fmaxf(a, b); }
+// minNum without the canonicalising v_max the compiler puts in front of fmin's operands (one per operand that is not known to
+// be quiet): v_min_f64 / v_min_f32 in the kernels' IEEE mode quiet a signalling NaN themselves.  Inner loops only.
+RV_DEV double m_min_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RV_DEV float  m_min_raw(float a, float b)  { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RV_DEV bool m_finite(double x) { return ::isfinite(x); }
 RV_DEV bool m_finite(float x)  { return ::isfinite(x); }
 
@@ -306,7 +314,7 @@ template <typename T> RV_DEV T sinh_pos(T x) {
 // Result of the catenary-parameter solve: C (NaN if none), u = l C / 2, r = sqrt(L^2-dH^2)/l -- so that sinh(u) = r u at
 // the root (reused by the tension rule and the shape samples) -- and e = exp(u) (carried out of the iteration: the shape
 // samples and the warm start of a nearby system need it, and the iteration has it for a handful of instructions).
-template <typename T> struct CatRoot { T C, u, r, e; };
+template <typename T> struct CatRoot { T C, u, r, e, sq; };   // sq = sqrt(L^2 - dH^2)
 
 // e^d for |d| < 2^-5 (fp64: Taylor to d^7, truncation < 2e-17 relative; fp32: to d^4, < 3e-10): how exp(u) is carried from
 // one Halley iterate to the next, u' = u + d, instead of being evaluated again.
@@ -316,6 +324,9 @@ RV_DEV double exp_increment(double d) {
     p = ::fma(p, d, 1.0 / 6); p = ::fma(p, d, 0.5); p = ::fma(p, d, 1.0);
     return ::fma(p, d, 1.0);
 }
+// the same for a converged iterate, |d| < 2^-15: to d^3 (< 2e-20 relative; the only literal is 1/6)
+RV_DEV double exp_increment_tiny(double d) { return ::fma(::fma(::fma(d, 1.0 / 6, 0.5), d, 1.0), d, 1.0); }
+RV_DEV float exp_increment_tiny(float d) { return ::fmaf(::fmaf(d, 0.5f, 1.0f), d, 1.0f); }
 RV_DEV float exp_increment(float d) {
     float p = ::fmaf(d, 1.0f / 24, 1.0f / 6);
     p = ::fmaf(p, d, 0.5f); p = ::fmaf(p, d, 1.0f);
@@ -336,9 +347,8 @@ RV_DEV float exp_increment(float d) {
 //    by two steps of u <- log(2 r u) when r > 8;
 //  * near-taut cables (u < 0.5) use the cancellation-free forms h = u (S(u) - (r-1)),
 //    h' = (cosh u - 1) - (r - 1) with r - 1 = (L2 - l^2) / (l (sqrt(L2) + l));
-//  * three iterations are unrolled (cubic convergence: the last step is < 2e-8 relative for
-//    every r <= 8); systems whose last step was still > 1e-6 keep iterating, so the result
-//    never depends on the unroll count;
+//  * two iterations are unrolled (cubic convergence from a start within 1 %: the second step is < 1e-6 relative for
+//    r < 4.5); systems whose last step was still > 1e-6 keep iterating, so the result never depends on the unroll count;
 //  * exp(u) is evaluated once: an iterate that moved by |d| < 2^-5 takes e^u e^d with the short polynomial of d (round 3:
 //    an exp is ~30 instructions, the increment 8; the rollout's per-node geometry ran seven exps, now two).
 // Warm start (WARM; u_warm, e_warm = exp(u_warm)): the root of a NEARBY system -- the rollout solves the same cable at
@@ -350,22 +360,32 @@ template <typename T, bool WARM>
 RV_DEV CatRoot<T> solve_catenary_root_impl(T l, T dH, T L, T c_lo, T c_hi, T u_warm, T e_warm) {
     const T L2 = L * L - dH * dH;
     const T sq = m_sqrtq(L2);
-    T r = m_div(sq, l);
-    T rm1 = m_div(L2 - l * l, l * (sq + l));
+    // 1 / l once, for r here and C at the end (l = 0 gives NaN, l = inf gives 0: either way not a valid system below, as
+    // with the quotients themselves)
+    const T il = fast_rcp(l);
+    T r = sq * il;
+    // r - 1 without cancellation; only the near-taut forms and the cold start need it (a warm solve away from u < 0.5 never does)
+    auto r_minus_1 = [&]() { return m_div(L2 - l * l, l * (sq + l)); };
     T u, e = T(-1);                  // e = exp(u) of the current iterate, or < 0: not known
     bool ok;
     bool warm = false;
     if (WARM) {
         const T chw = T(0.5) * (e_warm + fast_rcp(e_warm));          // (e_warm > 0 whenever u_warm > 0)
-        warm = u_warm > T(0) && chw > r && rm1 > T(0) && m_finite(r);
+        warm = u_warm > T(0) && chw > r && L2 > l * l && m_finite(r);
     }
     if (warm) {
         u = u_warm; e = e_warm;
         ok = true;
     } else {
-        u = m_sqrtq(m_max(T(60) * (T(-1.0 / 6.0) + m_sqrtq(T(1.0 / 36.0) + rm1 * T(1.0 / 30.0))), T(0)));
+        const T rm1 = r_minus_1();
+        // root of y/6 + y^2/120 = r - 1 in y = u^2 (an upper bound, exact to O(u^6)), then one Newton step on the series with
+        // its y^3/5040 term: the start is within 0.4 % of the root at r = 3.7 (2 % at r = 8) instead of 3 % (8 %), so that two
+        // Halley iterations reach the last bit where three were needed, and the second one already moves by |d| < 2^-5
+        T y = m_max(T(60) * (T(-1.0 / 6.0) + m_sqrtq(T(1.0 / 36.0) + rm1 * T(1.0 / 30.0))), T(0));
+        y = y - (y * y * y * T(1.0 / 5040)) * fast_rcp(T(1.0 / 6) + y * (T(1.0 / 60) + y * T(1.0 / 1680)));
+        u = m_sqrtq(y);
         ok = rm1 > T(0) && m_finite(r) && m_finite(u) && u > T(0);
-        if (!ok) { u = T(1); r = T(2); rm1 = T(1); }
+        if (!ok) { u = T(1); r = T(2); }
         if (r > T(8)) {
             T ul = m_log(T(2) * r * u);
             ul = m_log(T(2) * r * ul) + T(0.05);
@@ -373,9 +393,10 @@ RV_DEV CatRoot<T> solve_catenary_root_impl(T l, T dH, T L, T c_lo, T c_hi, T u_w
         }
     }
     bool moving = true;               // the last step changed u by more than 1e-6 relative
-    auto halley = [&]() {
+    auto halley = [&](auto LAST) {       // LAST: the last unrolled iteration -- a converged step carries exp(u) by the short form
         T h, hp, sh;
         if (u < T(0.5)) {
+            const T rm1 = ok ? r_minus_1() : T(1);
             const T u2 = u * u;
             const T S = sinhc_m1_small(u2);
             sh = u * (T(1) + S);
@@ -393,16 +414,16 @@ RV_DEV CatRoot<T> solve_catenary_root_impl(T l, T dH, T L, T c_lo, T c_hi, T u_w
         if (!(m_finite(un) && un > T(0))) un = u;
         const T d = un - u;
         moving = m_abs(d) > T(1e-6) * un;
-        e = (e > T(0) && m_abs(d) < T(0.03125)) ? e * exp_increment(d) : T(-1);
+        if (LAST.value && !moving && m_abs(d) < T(3e-5)) e = e > T(0) ? e * exp_increment_tiny(d) : T(-1);
+        else e = (e > T(0) && m_abs(d) < T(0.03125)) ? e * exp_increment(d) : T(-1);
         u = un;
     };
-    halley(); halley();
-    if (!WARM) halley();
-    for (int it = 0; it < 40 && moving && ok; ++it) halley();
+    halley(BoolC<false>{}); halley(BoolC<true>{});
+    for (int it = 0; it < 40 && moving && ok; ++it) halley(BoolC<false>{});
     if (e < T(0)) e = m_exp(u);                                      // (near-taut roots, u < 0.5: the series path carries no exp)
-    const T C = m_div(T(2) * u, l);
+    const T C = (T(2) * u) * il;
     const bool in = ok && C >= c_lo && C <= c_hi;
-    return {in ? C : m_nan<T>(), u, r, e};
+    return {in ? C : m_nan<T>(), u, r, e, sq};
 }
 
 template <typename T> RV_DEV CatRoot<T> solve_catenary_root(T l, T dH, T L, T c_lo, T c_hi) {
@@ -419,7 +440,7 @@ template <typename T> RV_DEV T solve_catenary_C(T l, T dH, T L, T c_lo, T c_hi) 
 // Tension rule of main_fun.py:302-305: T = (w/L) l / (2 sinh(C l / 2)), NaN -> (w/L) l / 2.
 // At the root sinh(C l / 2) = sinh(u) = r u, which the solve already holds.
 template <typename T> RV_DEV T cable_tension(T l, CatRoot<T> c, T w_per_len) {
-    return (c.C == c.C) ? m_div(w_per_len * l, T(2) * c.r * c.u) : w_per_len * l / T(2);
+    return (c.C == c.C) ? (w_per_len * l) * fast_rcp(T(2) * c.r * c.u) : w_per_len * l / T(2);     // (valid root: r u = sinh u > 0, finite)
 }
 
 // Lowest z (in the "up" sense) of transform_catenary(A, A+rel, Catenary(L), theta, gamma)[3]
@@ -460,20 +481,22 @@ RV_DEV T augmented_finish(const AugShape<T> &a, CatRoot<T> c, T L, int M, T inv_
     T best;
     if (c.C == c.C) {
         // a valid root means L^2 - dH'^2 > l'^2 > 0: every quantity inverted below is finite and positive
-        T E = m_sqrtq(m_div(L + a.dHp, L - a.dHp)) * fast_rcp(c.e);    // e^{a}
+        // e^{a} = sqrt((L + dH') / (L - dH')) e^{-u'} = (L + dH') / (sqrt(L^2 - dH'^2) e^{u'}): root and exp come with the solve
+        T E = (L + a.dHp) * fast_rcp(c.sq * c.e);
         T Ei = fast_rcp(E);
         const T Ed = m_exp(T(2) * c.u * inv_Mm1), Edi = fast_rcp(Ed);
         const T hx = up * (a.m.x * a.Bp.x + a.m.y * a.Bp.y);   // horizontal part of m . q_j is t_j * hx (up = +-1 folded in:
-        const T mz = m_div(a.m.z, c.C);                        //  the reference's mz carries up as well, up * up = 1)
+        const T mz = a.m.z * fast_rcp(c.C);                    //  the reference's mz carries up as well, up * up = 1)
         const T sa = hx * inv_Mm1, sb = T(0.5) * mz;
         T lin = -(sb * (E + Ei));                        // c0; + a per sample
         T z = T(0);                                      // sample 0 is the anchor itself
         best = T(0);
+#pragma unroll 3
         for (int j = 1; j < M; ++j) {
             E *= Ed; Ei *= Edi;
             lin += sa;
             z = m_fma(sb, E + Ei, lin);
-            best = m_min(best, z);                       // minNum: a NaN operand is dropped; see above
+            best = m_min_raw(best, z);                   // minNum: a NaN operand is dropped; see above
         }
         const T chk = z + ((hx - hx) + (mz - mz));       // NaN iff a sample was (or hx / mz is not finite)
         if (chk != chk) best = m_nan<T>();

@@ -54,7 +54,6 @@ constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + un
 // Scalars of one handle, resident in device memory and read with scalar loads where they are
 // used.  Passing them by value as kernel arguments kept ~60 SGPRs live across the whole kernel
 // and pushed the sequential phase's loop into SGPR spills (v_writelane/v_readlane per step).
-template <bool B> struct BoolC { static constexpr bool value = B; };   // compile-time flag for generic lambdas
 
 template <typename T> struct RolloutConsts {
     T h, vs_h, inv_h, L, w_per_len, c_lo, c_hi, up, vs, inv_Mm1;       // inv_Mm1 = 1 / (n_shape_pts - 1)
@@ -443,7 +442,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
-    const RolloutConsts<T> &kk = *a.k;
+    // The handle's scalars live in device memory that nothing writes while a kernel runs.  fp32: read through the CONSTANT
+    // address space they become scalar loads (s_load, SGPR results, placed where they are used) instead of the vector loads
+    // the compiler must issue for memory it cannot prove unclobbered across the kernel's LDS and global stores (C3:
+    // 52.5 -> 51.8 us).  fp64: the same change costs more in spilled SGPRs than the loads cost (42 -> 86 spill slots,
+    // B = 64: 371 -> 380 us, measured on one box), so the fp64 kernels keep the plain pointer.
+    typedef const RolloutConsts<T> __attribute__((address_space(4))) *ConstsPtrK;
+    typedef const RolloutConsts<T> *ConstsPtrG;
+    typedef typename RvCond<sizeof(T) == 4, ConstsPtrK, ConstsPtrG>::type ConstsPtr;
+    const auto &kk = *(ConstsPtr)a.k;
     const int tid = threadIdx.x, NT = a.NT;
     const int k0 = blockIdx.x * CK;
     // Batched launch (rovmpc_step_batch_device): blockIdx.y = problem.  Every per-problem array is the single-problem
@@ -649,7 +656,6 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             vz = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
         } else { vx = u[0]; vy = u[1]; vz = u[2]; }
     };
-    const int p2rem = (N + 1) % max(LNT >> cks, 1);    // nodes of the partial last round of phase 2a
     // (compiled-in model: the gamma wave integrates gamma and fills its table meanwhile)
     if (gwave) {
         RV_STAMP_W(8);
@@ -672,21 +678,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
         RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10);
     }
-    for (int i = (wideB && gwave) ? (N + 1) * CK : ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
-        // node order: an item's cost grows with n (an n-term position sum), and the last round is partial.
-        // Full rounds take the far nodes in ascending order (the first waves -- the theta wave among them --
-        // get the cheaper ones), the partial round the nodes next to the anchor, again first waves first.
-        const int q = i >> cks, c = i & ckm;
-        const int n = q < N + 1 - p2rem ? p2rem + q : q - (N + 1 - p2rem);
-        // position of node n: P_0 + sum_{j<n} (v_scale dt) U_j, accumulated in the reference's
-        // sequential order by the item itself (independent LDS reads, no scan, no extra barrier)
-        T Px = P1x0, Py = P1y0, Pz = P1z0;
-        {
-            const T *u = &sU[c * US];
-            for (int j = 0; j < n; ++j) {
-                Px = Px + kk.vs_h * u[3 * j]; Py = Py + kk.vs_h * u[3 * j + 1]; Pz = Pz + kk.vs_h * u[3 * j + 2];
-            }
-        }
+    // One thread takes `p2m` CONSECUTIVE nodes of one candidate: the position of its first node is the n-term sum
+    //   P_n = P_0 + sum_{j<n} (v_scale dt) U_j
+    // in the reference's sequential order, every further node one more term of the same sum -- bit-identical to summing each
+    // node from scratch, which is what round 2 did, one node per thread and round (an O(N^2) pass: a third of phase 2's
+    // instructions at N = 20).  No scan, no extra barrier.
+    auto node_item = [&](int n, int c, T Px, T Py, T Pz) {
         RV_PL(sP, 0, n, c) = Px; RV_PL(sP, 1, n, c) = Py; RV_PL(sP, 2, n, c) = Pz;
         const T rx = Px - P0x, ry = Py - P0y, rz = Pz - P0z;                 // simply.py:25
         {
@@ -705,7 +702,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PX(0, n, c) = x3;
                 if (!Trig<T>::bounded(m_abs(x3))) s_prog[0] = 1;             // a sine argument of the theta chain is huge (or NaN)
             }
-            continue;
+            return;
         }
         const T nr = m_sqrt(rx * rx + ry * ry + rz * rz);
         const T inr = T(1) / (nr + T(1e-8));                                 // :26
@@ -715,7 +712,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // [v_sway, v_surge, a_sway, a_surge, V(3), a(3)], velocities in m/s
             if (VT == ROVMPC_VT_COMPOSE) {       // V depends on (theta, gamma): rows are built beside the integration
                 RV_PL(sA, 5, n, c) = ux; RV_PL(sA, 6, n, c) = uy; RV_PL(sA, 7, n, c) = uz;
-                continue;
+                return;
             }
             // the neighbour node of the first difference: n - 1, or node 1 for n = 0 (np.gradient's edge rule, :846-847)
             const int m = n == 0 ? 1 : n - 1;
@@ -742,7 +739,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 #pragma unroll
             for (int p = 0; p < 10; ++p)
                 if (uses(p)) RV_PX(p, n, c) = (row[p] - sMean[4 + p]) * sInv[4 + p];
-            continue;
+            return;
         }
         const T tension = m_clip(nr, T(1e-5), T(10));                        // :27
         if (uses(0)) RV_PX(0, n, c) = (Px - sMean[0]) * sInv[0];
@@ -772,6 +769,37 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (uses(7)) RV_PX(7, n, c) = (Ay - sMean[7]) * sInv[7];
             if (uses(8)) RV_PX(8, n, c) = (Az - sMean[8]) * sInv[8];
             if (uses(13)) RV_PX(13, n, c) = (ap - sMean[apslot]) * sInv[apslot];
+        }
+    };
+    if (MODEL == MODEL_BUILTIN) {
+        const int p2m = ((N + 1) * CK + LNT - 1) / LNT;          // nodes per thread
+        const int c = ltid & ckm, n0 = (ltid >> cks) * p2m;
+        if (!(wideB && gwave) && !(a.debug & 4) && n0 <= N) {
+            T Px = P1x0, Py = P1y0, Pz = P1z0;
+            const T *u = &sU[c * US];
+            for (int j = 0; j < n0; ++j) {
+                Px = Px + kk.vs_h * u[3 * j]; Py = Py + kk.vs_h * u[3 * j + 1]; Pz = Pz + kk.vs_h * u[3 * j + 2];
+            }
+            const int n1 = min(n0 + p2m, N + 1);
+            for (int n = n0; n < n1; ++n) {
+                if (n > n0) { Px = Px + kk.vs_h * u[3 * n - 3]; Py = Py + kk.vs_h * u[3 * n - 2]; Pz = Pz + kk.vs_h * u[3 * n - 1]; }
+                node_item(n, c, Px, Py, Pz);
+            }
+        }
+    } else {
+        // loaded models: one node per thread and round (their items carry the feature rows; measured: the consecutive-node
+        // form above costs them 0.5 us at C2).  Full rounds take the far nodes in ascending order, the partial last round the
+        // nodes next to the anchor (an item's cost grows with n).
+        const int p2rem = (N + 1) % max(LNT >> cks, 1);
+        for (int i = ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
+            const int q = i >> cks, c = i & ckm;
+            const int n = q < N + 1 - p2rem ? p2rem + q : q - (N + 1 - p2rem);
+            T Px = P1x0, Py = P1y0, Pz = P1z0;
+            const T *u = &sU[c * US];
+            for (int j = 0; j < n; ++j) {
+                Px = Px + kk.vs_h * u[3 * j]; Py = Py + kk.vs_h * u[3 * j + 1]; Pz = Pz + kk.vs_h * u[3 * j + 2];
+            }
+            node_item(n, c, Px, Py, Pz);
         }
     }
     RV_STAMP(12);
