@@ -900,12 +900,15 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const int r = (N * CK) % 256;
         if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
     }
+    // Long horizons (compiled-in model, one theta wave): when the join would leave MORE than one round of phase 4b, the
+    // geometry waves chase the theta wave instead -- every pool thread owns the items tid, tid + pool, ..., takes them through
+    // 4a at once and through 4b as soon as the theta wave has passed their node, so that after the last integration step only
+    // the last nodes' batch is left (C3, N = 50: two rounds = 3.7 us after the join -> one batch).  With a single round left
+    // (C2, the throughput geometries) the chase gains nothing -- that round runs on every SIMD after the join, a chased batch
+    // on one -- and the extra waves slow the integrating one (measured in round 1): those keep the early batch only.
+    const bool chase = MODEL == MODEL_BUILTIN && CK <= 16 && wideB && N * CK - early > NT;
     // the integrating wave reports its progress only as far as somebody waits for it (the nodes of the early batch)
-    const int prog_until = early > 0 ? (early + CK - 1) / CK : 0;
-    // Measured and rejected: letting the geometry waves chase the integrating wave node by node
-    // (LDS progress flags) -- a phase-4b item is a ~4 us dependent chain whatever the lane count, so
-    // the tail after the last integration step does not shrink and the extra waves slow the
-    // integrating one; phase 4b stays one parallel round after the join.
+    const int prog_until = chase ? N : (early > 0 ? (early + CK - 1) / CK : 0);
     if (MODEL == MODEL_BUILTIN) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
@@ -1054,13 +1057,18 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // are therefore taken through 4a AND 4b by an otherwise idle wave while the integration is
         // still running; the join then leaves a multiple of 256.
         const int j = wide ? tid - nint - 64 : -1;
-        const bool own = j >= 0 && j < early && !(a.debug & 2);
-        if (!wide || tid >= nint) geometry_a(own ? j : -1, wide ? tid - nint : tid, wide ? NT - nint : NT, early);
-        if (own) {
-            const int n = j >> cks;
+        const bool own = !chase && j >= 0 && j < early && !(a.debug & 2);
+        if (!wide || tid >= nint) geometry_a(own ? j : -1, wide ? tid - nint : tid, wide ? NT - nint : NT, chase ? 0 : early);
+        // phase 4b before the join: the early batch's item, or -- chasing -- all of this pool thread's items in node order
+        int b0 = 0, b1 = 0, bs = 1;
+        if (chase) { if (tid >= nint && !(a.debug & 2)) { b0 = tid - nint; b1 = N * CK; bs = NT - nint; } }
+        else if (own) { b0 = j; b1 = j + 1; }
+        for (int i = b0; i < b1; i += bs) {
+            const int n = i >> cks;
             while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
-            geometry_b_item(n, j & ckm);
+            geometry_b_item(n, i & ckm);
         }
+        if (chase) early = N * CK;                    // nothing is left for the round after the join
     } else {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
         const int nint = 64;

@@ -16,7 +16,8 @@ DBG = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 CKB = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 NTB = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 MODEL = sys.argv[6] if len(sys.argv) > 6 else "default"        # default | gen2 | gen3 | rows:CT,CG | jit-default
-cfg = rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG, candidates_per_block=CKB, threads_per_block=NTB)
+DTYPE = os.environ.get("STAMPS_DTYPE", "f64")
+cfg = rovmpc.MPCConfig(N=N, K=K, debug_flags=DBG, candidates_per_block=CKB, threads_per_block=NTB, dtype=DTYPE)
 model = rovmpc.default_model()
 if MODEL == "gen2":
     model = rovmpc.generation2_model(); cfg.feature_map = rovmpc.FEATURES_GEN2
@@ -28,13 +29,13 @@ elif MODEL == "jit-default":
     cfg.no_builtin = True
 eng = rovmpc.Engine(cfg, model)
 print("model", MODEL, "->", eng.model_path)
-state, U = rovmpc.synthetic_problem(K, N)
+state, U = rovmpc.synthetic_problem(K, N, dtype=cfg.np_dtype)
 for _ in range(5):
     eng.step(state, U)
 if os.environ.get("STAMPS_BACK_TO_BACK"):        # steady state: launches back to back on one stream, stamps of the last one
     import torch
     dev = torch.device("cuda", 0)
-    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev)
+    d_state = torch.tensor(state, device=dev); d_U = torch.tensor(U, device=dev, dtype=torch.float64 if DTYPE == "f64" else torch.float32)
     d_res = torch.empty(eng.result_len, dtype=torch.float64, device=dev)
     for _ in range(int(os.environ["STAMPS_BACK_TO_BACK"])):
         eng.step_device(d_state.data_ptr(), d_U.data_ptr(), d_res.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -57,6 +58,16 @@ for i, n in enumerate(names):
     if len(col) == 0:
         continue
     print(f"  {n:18s} median {np.median(col - t0) / 100:7.2f}   min {(col.min() - t0) / 100:7.2f}   max {(col.max() - t0) / 100:7.2f}")
+
+print("per workgroup, us after ITS OWN start (median / p10 / p90):")
+for i, n in enumerate(names):
+    if n is None or i == 0:
+        continue
+    m = st[:, i] > 0
+    if not m.any():
+        continue
+    dl = (st[m, i] - st[m, 0]) / 100
+    print(f"  {n:32s} {np.median(dl):7.2f} {np.percentile(dl, 10):7.2f} {np.percentile(dl, 90):7.2f}")
 
 # residency: which CU ran each workgroup (HW_ID / XCC_ID stamp), how many were alive together
 hw = buf[:nb.value, 2]
