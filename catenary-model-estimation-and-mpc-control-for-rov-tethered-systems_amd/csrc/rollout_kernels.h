@@ -546,17 +546,28 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         else if (hold) run(BoolC<true>{}, BoolC<false>{});
         else run(BoolC<false>{}, BoolC<false>{});
     };
-    auto gamma_sines = [&]() {
-        const int lane = tid & 63;
+    // G_n = sinA + 4 sinM + sinE (RK4; sinA for Euler), sinA_n = sin(x17 at t_n) = row n-1's [3]
+    auto gamma_G = [&](int first, int stride) {
         const int nsteps = (a.debug & 1) ? 0 : N;
         const bool hold = a.prev_mode == ROVMPC_PREV_HOLD, euler = a.integrator == ROVMPC_EULER;
+        for (int n = first; n < nsteps; n += stride) {
+            const T sinA = n == 0 ? sG[8 * N] : sG[8 * (n - 1) + 3];
+            const T sinM = hold ? sinA : sG[8 * n + 4], sinE = hold ? sinA : sG[8 * n + 3];
+            sG[8 * n + 2] = euler ? sinA : (sinA + sinE) + T(4) * sinM;
+        }
+    };
+    // (first, stride): the items this thread evaluates -- the gamma wave's lanes alone, or, for long horizons, every thread of
+    // the workgroup once the chain is through (share_sines below); with_G: the G_n pass follows at once (it reads every sine:
+    // shared sines leave it to phase 2b, behind the barrier)
+    auto gamma_sines = [&](int first, int stride, bool with_G) {
+        const int nsteps = (a.debug & 1) ? 0 : N;
         const Trig<T> trig(true);
         const T m17 = sMean[17], i17 = sInv[17];
         // item 3n + r -- r = 0 sincos(gamma_n), 1 sin(x17 at t_n+1), 2 sin(x17 at the midpoint); the last
         // item is sin(x17 at t_0).  One wave's DS operations complete in order, so the reads see the
         // chain's stores.
         // (and one more: sincos(gamma_N), which only the geometry of the last node reads -- row N, slots 2 / 3)
-        for (int i = lane; i <= 3 * nsteps + (nsteps > 0 ? 1 : 0); i += 64) {
+        for (int i = first; i <= 3 * nsteps + (nsteps > 0 ? 1 : 0); i += stride) {
             const bool last = i == 3 * nsteps + 1;
             const int n = last ? nsteps : (i == 3 * nsteps ? 0 : i / 3), r = last ? 0 : (i == 3 * nsteps ? 3 : i - 3 * n);
             const T g_n = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
@@ -569,13 +580,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             else if (r == 3) sG[8 * N] = sv;
             else sG[8 * n + 2 + r] = sv;
         }
-        // G_n = sinA + 4 sinM + sinE (RK4; sinA for Euler), sinA_n = sin(x17 at t_n) = row n-1's [3]
-        for (int n = lane; n < nsteps; n += 64) {
-            const T sinA = n == 0 ? sG[8 * N] : sG[8 * (n - 1) + 3];
-            const T sinM = hold ? sinA : sG[8 * n + 4], sinE = hold ? sinA : sG[8 * n + 3];
-            sG[8 * n + 2] = euler ? sinA : (sinA + sinE) + T(4) * sinM;
-        }
+        if (with_G) gamma_G(first, stride);
     };
+    // sines shared by the whole workgroup: when they are more than one pass of the gamma wave (3 N + 2 > 64) and phase 2 is
+    // bounded by that wave (C3, N = 50: chain 3.2 us + three passes 1.8 us against 1.3 us of phase 2a) the other waves, idle
+    // at the barrier, take their share as soon as the chain is through (LDS flag): one pass instead of three
+    const bool share_sines = wideB && 3 * N + 2 > 64;
+    int *s_chain_done = s_best_c + 6;
 
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
     // (compiled-in model, wide workgroup: the gamma wave has nothing to fetch)
@@ -632,7 +643,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
         }
         if (tid < 18) { sMean[tid] = kk.mean[tid]; sInv[tid] = kk.inv_scale[tid]; }
-        if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; }
+        if (tid == 0) { s_prog[0] = 0; s_prog[1] = 0; s_best_c[6] = 0; }
     }
     // state (uniform loads), behind the controls' loads
     P0x = (T)sd_at(0); P0y = (T)sd_at(1); P0z = (T)sd_at(2);
@@ -676,7 +687,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
             if ((tid & 63) == 0) sG[8 * N + 1] = ga0;           // phase 2b's gamma_0 (this wave alone knows it)
         }
-        RV_STAMP_W(9); gamma_sines(); RV_STAMP_W(10);
+        RV_STAMP_W(9);
+        if (share_sines) { if ((tid & 63) == 0) __hip_atomic_store(s_chain_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else gamma_sines(tid & 63, 64, true);
+        RV_STAMP_W(10);
     }
     // One thread takes `p2m` CONSECUTIVE nodes of one candidate: the position of its first node is the n-term sum
     //   P_n = P_0 + sum_{j<n} (v_scale dt) U_j
@@ -803,9 +817,14 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
     }
     RV_STAMP(12);
+    if (MODEL == MODEL_BUILTIN && share_sines) {
+        if (!gwave) while (__hip_atomic_load(s_chain_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+        gamma_sines(tid, NT, false);
+    }
     __syncthreads();
     RV_STAMP(13);
     if (MODEL == MODEL_BUILTIN) {
+        if (share_sines) gamma_G(tid, NT);           // (its reads are the shared sines; the theta chain reads it behind the next barrier)
         // ---- phase 2b: what hangs on gamma_n alone, for every (node, candidate): the gamma plane and the
         // first half of the velocity transform ------------------------------------------------------------
         // v_cat = R_theta(+theta_n) R_gamma(-gamma_n) u_n about the cable axes of node n (R @ v of
