@@ -33,7 +33,7 @@ PKG = os.path.join(ROOT, "catenary-model-estimation-and-mpc-control-for-rov-teth
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec): 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
-PROFILE_TAG = "r02"             # profiles/<tag>_pmc_summary.json is the PMC pass the roofline block may quote
+PROFILE_TAG = "r03"             # profiles/<tag>_pmc_summary.json is the PMC pass the roofline block may quote
 
 
 def kernel_sources_sha16():
@@ -648,10 +648,16 @@ def main():
                                "kernel_event_pair_min_us": kev_min_ms * 1e3 if kev_min_ms else None,
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "binding_bound": "fp64-valu issue / dependent-chain latency (see valu_f64); HBM is the bound BASELINE.json "
-                                                "asks to be reported, not the one that limits this kernel (~2-3 kFLOP per 24.4 B)"}
+                                                "asks to be reported, not the one that can limit this kernel: at ~1.5 kFLOP of fp64 per "
+                                                "24.4 algorithmic bytes even 100 % of the 78.6 TFLOP/s fp64 vector peak moves 78.6e12 / 1.5e3 "
+                                                "x 24.4 B = 1.3 TB/s = 16 % of HBM peak, so BASELINE's 40 % HBM target is out of reach by "
+                                                "arithmetic; the figures to drive are valu_f64.frac and the chain latency"}
             if (args.N, args.K, args.dtype, world) == (20, 4096, "f64", 1) and args.model == "default" and args.debug_flags == 0:
                 bench_extras.attach_pmc(out["roofline"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json"), sha,
                                         kavg_ms * 1e-3, FP64_VECTOR_PEAK_TFLOPS)
+            if (args.N, args.K, args.dtype, world) == (50, 16384, "f32", 1) and args.model == "default" and args.debug_flags == 0:
+                bench_extras.attach_pmc(out["roofline"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary_C3.json"), sha,
+                                        kavg_ms * 1e-3, FP64_VECTOR_PEAK_TFLOPS, dtype="f32")
         if world == 1 and smpc is None and S == 1 and not args.no_pipelined_extra:
             # extra, not the headline: two independent MPC steps in flight on one GPU (second engine handle
             # on a high-priority stream = its own hardware queue), so one step's launch ramp / arg-min tail
@@ -682,7 +688,9 @@ def main():
             del st2, pair                     # (every live stream competes for the runtime's few hardware queues)
         default_size = (args.N, args.K, args.dtype, args.model) == (20, 4096, "f64", "default") and args.debug_flags == 0
         if world == 1 and smpc is None and S == 1 and default_size and not args.no_extras:
-            bench_extras.run_extras(out, args, cfg, model, dev)
+            bench_extras.run_extras(out, args, cfg, model, dev,
+                                    pmc_ctx={"dir": os.path.join(ROOT, "profiles"), "tag": PROFILE_TAG, "sha": sha,
+                                             "hbm_peak": HBM_PEAK_GBS, "fp64_peak": FP64_VECTOR_PEAK_TFLOPS})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.N)
         print(json.dumps(out))

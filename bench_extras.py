@@ -14,9 +14,11 @@ import time
 import numpy as np
 
 
-def attach_pmc(roof, pmc_path, sha, kernel_s, fp64_peak_tflops, n_simd=1024, clk_hz=2.4e9):
-    """HBM traffic and the fp64-VALU bound from rocprofv3 --pmc passes of this same command (tools/profile_round.sh).
-    The summary carries the hash of the kernel sources it was taken on; a summary of another build is NOT quoted."""
+def attach_pmc(roof, pmc_path, sha, kernel_s, fp64_peak_tflops, n_simd=1024, clk_hz=2.4e9, dtype="f64", fp32_peak_tflops=157.3):
+    """HBM traffic and the VALU bound from rocprofv3 --pmc passes of this same command (tools/profile_round.sh,
+    tools/profile_regime.sh).  The summary carries the hash of the kernel sources it was taken on; a summary of another build
+    is NOT quoted.  dtype f64: `valu_f64` against the fp64 vector peak; f32: `valu_f32` against the fp32 vector peak (a
+    packed-issue figure: v_pk_fma_f32 does two FMAs per lane)."""
     if not os.path.exists(pmc_path):
         roof["traffic_source"] = f"none: {os.path.basename(pmc_path)} not present"
         return
@@ -31,25 +33,33 @@ def attach_pmc(roof, pmc_path, sha, kernel_s, fp64_peak_tflops, n_simd=1024, clk
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # MI355X_MICROARCH.md: KiB units; FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream on gfx950
         roof["traffic"] = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-    f64 = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"]
-    if all(k in pmc for k in f64) and kernel_s > 0:
-        fma, add, mul, trans = (pmc[k]["mean"] for k in f64)
+    sfx = "F64" if dtype == "f64" else "F32"
+    keys = [f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_TRANS_{sfx}"]
+    if all(k in pmc for k in keys) and kernel_s > 0:
+        fma, add, mul, trans = (pmc[k]["mean"] for k in keys)
         flop = 64.0 * (2.0 * fma + add + mul + trans)            # lane slots of the wave-instructions, exec mask ignored
-        n64 = fma + add + mul + trans
-        v = {"achieved_tflops": flop / kernel_s / 1e12, "peak_tflops": fp64_peak_tflops,
-             "frac": flop / kernel_s / 1e12 / fp64_peak_tflops,
-             "f64_wave_instructions_per_launch": n64,
-             "note": "flop = 64 x (2 FMA + ADD + MUL + TRANS) wave-instructions per launch / this run's kernel time"}
+        nfl = fma + add + mul + trans
+        peak = fp64_peak_tflops if dtype == "f64" else fp32_peak_tflops
+        v = {"achieved_tflops": flop / kernel_s / 1e12, "peak_tflops": peak,
+             "frac": flop / kernel_s / 1e12 / peak,
+             f"{dtype}_wave_instructions_per_launch": nfl,
+             "note": f"flop = 64 x (2 FMA + ADD + MUL + TRANS) {dtype} wave-instructions per launch / this run's kernel time"
+                     + ("" if dtype == "f64" else "; the fp32 vector peak counts packed v_pk_fma_f32 (2 FMA per lane): a scalar-f32 "
+                        "instruction stream tops out at half of it")}
         if "SQ_INSTS_VALU" in pmc:
             # issue slots: an fp64 wave-instruction holds its SIMD's vector issue 4 cycles (16 lanes/clk), any other 2
-            busy = (4.0 * n64 + 2.0 * max(pmc["SQ_INSTS_VALU"]["mean"] - n64, 0.0)) / (n_simd * kernel_s * clk_hz)
+            nv = pmc["SQ_INSTS_VALU"]["mean"]
+            busy = ((4.0 * nfl + 2.0 * max(nv - nfl, 0.0)) if dtype == "f64" else 2.0 * nv) / (n_simd * kernel_s * clk_hz)
             v["issue_busy_frac"] = busy
-            v["valu_wave_instructions_per_launch"] = pmc["SQ_INSTS_VALU"]["mean"]
-        roof["valu_f64"] = v
+            v["valu_wave_instructions_per_launch"] = nv
+            v["non_float_share_of_valu"] = max(nv - nfl, 0.0) / nv if nv else None
+        roof["valu_" + dtype] = v
     if "SQ_WAVE_CYCLES" in pmc and "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
         wc = pmc["SQ_WAVE_CYCLES"]["mean"]
         roof["wave_cycles_waiting_frac"] = pmc["SQ_WAIT_ANY"]["mean"] / wc
         roof["wave_cycles_valu_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["mean"] / wc
+    if "SQ_LDS_BANK_CONFLICT" in pmc and "SQ_LDS_IDX_ACTIVE" in pmc and pmc["SQ_LDS_IDX_ACTIVE"]["mean"] > 0:
+        roof["lds_bank_conflict_frac"] = pmc["SQ_LDS_BANK_CONFLICT"]["mean"] / pmc["SQ_LDS_IDX_ACTIVE"]["mean"]
 
 
 def _timed(fn, n, warm, sync):
@@ -63,7 +73,7 @@ def _timed(fn, n, warm, sync):
     return (time.perf_counter() - t0) / n
 
 
-def run_extras(out, args, cfg, model, dev):
+def run_extras(out, args, cfg, model, dev, pmc_ctx=None):
     import torch
     import rovmpc
     N, K = args.N, args.K
@@ -90,8 +100,18 @@ def run_extras(out, args, cfg, model, dev):
             eng.step_device(d_states[b].data_ptr(), d_U[b].data_ptr(), single.data_ptr(), stream)
             sync()
             same = same and bool(torch.equal(single, d_res[b]))
-        batched.append({"B": B, "value": B * K * N / per, "ms_per_launch": 1e3 * per,
-                        "records_bit_equal_to_single_launches": same})
+        run = {"B": B, "value": B * K * N / per, "ms_per_launch": 1e3 * per,
+               "records_bit_equal_to_single_launches": same}
+        if B == 64 and pmc_ctx is not None:
+            esz = 8 if cfg.dtype == "f64" else 4
+            alg = B * (K * N * 3 * esz + K * esz)
+            roof = {"bound": "hbm", "achieved": alg / per / 1e9, "peak": pmc_ctx["hbm_peak"], "unit": "GB/s",
+                    "frac": alg / per / 1e9 / pmc_ctx["hbm_peak"], "traffic": None, "algorithmic_bytes_per_launch": alg,
+                    "launch_s": per}
+            attach_pmc(roof, os.path.join(pmc_ctx["dir"], f"{pmc_ctx['tag']}_pmc_summary_B64.json"), pmc_ctx["sha"], per,
+                       pmc_ctx["fp64_peak"], dtype=cfg.dtype)
+            run["roofline"] = roof
+        batched.append(run)
         del d_U
     out["batched"] = {"unit": "horizon-steps/s", "runs": batched,
                       "note": "B independent C2-sized problems (own state, own candidates) per rovmpc_step_batch_device launch"}

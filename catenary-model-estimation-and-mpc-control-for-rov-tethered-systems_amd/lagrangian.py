@@ -156,7 +156,9 @@ def differentiate(node: ast.AST, var: str) -> ast.AST:
         if fn == "sqrt":
             return _div(du, _mul(_num(2.0), _call("sqrt", u)))
         if fn in ("abs", "Abs"):
-            return _mul(_div(u, _call("abs", u)), du)              # sign(u), as sympy differentiates Abs for real u
+            # sign(u), as sympy differentiates Abs for real u -- sign(0) = 0 there, so not u / |u| (0 / 0): the denominator is
+            # |u| + 1e-300, which leaves every quotient with |u| >= 1e-284 unchanged to the last bit
+            return _mul(_div(u, _add(_call("abs", u), ast.Constant(1e-300))), du)
         if fn == "square":
             return _mul(_mul(_num(2.0), u), du)
         if fn == "neg":
@@ -218,12 +220,40 @@ def euler_lagrange(lagrangian: str, variable_names: Optional[Sequence[str]] = No
 
     def solve(own, cross, rest):
         # sp.solve(EOM, ddq)[0] = -(rest + cross * ddq_other) / own; the reference lambdifies it over (theta, gamma, dtheta,
-        # dgamma) only, so a surviving cross term (or a vanishing own coefficient) means "not isolable" there too
-        if _is_num(own, 0.0) or not _is_num(cross, 0.0):
-            return None
-        return _text(_div(_neg(rest), own))
+        # dgamma) only, so a surviving cross term means "not isolable" there too.  Whether a coefficient vanishes is decided
+        # as sympy's simplification would: syntactically, or -- for one that is zero only after like terms cancel --
+        # numerically on sample points.  A vanishing own coefficient: sp.solve returns [] and the reference's pipeline
+        # (lagrangian_pipeline.py:150-153, 168-171) catches the IndexError and integrates with zero acceleration; here that is
+        # the string "0.0" with `vanishing` recorded, and lagrangian_rollout(on_unsolvable=...) decides what to do with it.
+        if not (_is_num(cross, 0.0) or _vanishes(cross)):
+            return None, False
+        if _is_num(own, 0.0) or _vanishes(own):
+            return "0.0", True
+        return _text(_div(_neg(rest), own)), False
 
-    return EulerLagrange(_text(L), _text(e_th), _text(e_ga), solve(a_tt, a_tg, r_th), solve(a_gg, a_gt, r_ga))
+    (acc_t, van_t), (acc_g, van_g) = solve(a_tt, a_tg, r_th), solve(a_gg, a_gt, r_ga)
+    el = EulerLagrange(_text(L), _text(e_th), _text(e_ga), acc_t, acc_g)
+    el.vanishing = (van_t, van_g)
+    return el
+
+
+
+def _vanishes(node: ast.AST) -> bool:
+    """True when the expression over x0..x5 evaluates to (numerically) zero on sample points although it is not the literal 0:
+    a coefficient such as x0 - x0 or sin(x1)**2 + cos(x1)**2 - 1, which sympy's solve would cancel."""
+    rng = np.random.default_rng(12345)
+    pts = rng.uniform(-2.0, 2.0, size=(6, 64))
+    ns = {"sin": np.sin, "cos": np.cos, "tanh": np.tanh, "exp": np.exp, "log": lambda v: np.log(np.abs(v) + 1e-300),
+          "sqrt": lambda v: np.sqrt(np.abs(v)), "abs": np.abs, "Abs": np.abs, "square": np.square, "neg": np.negative}
+    ns.update({f"x{i}": pts[i] for i in range(6)})
+    try:
+        with np.errstate(all="ignore"):
+            v = np.asarray(eval(compile(ast.Expression(ast.fix_missing_locations(node)), "<coefficient>", "eval"), {"__builtins__": {}}, ns),
+                           dtype=np.float64)
+    except Exception:                                     # noqa: BLE001 -- anything odd: treat as non-zero (the syntactic rule stands)
+        return False
+    v = np.broadcast_to(v, (64,)) if v.ndim == 0 else v
+    return bool(np.all(np.isfinite(v)) and np.max(np.abs(v)) < 1e-12)
 
 
 def _compile(text: str, n_features: int) -> Tuple[Program, List[float]]:
@@ -248,7 +278,7 @@ def el_residuals(lagrangian: str, theta, gamma, dtheta, dgamma, ddtheta, ddgamma
 
 
 def lagrangian_rollout(lagrangian: str, time, theta0, gamma0, vtheta0, vgamma0,
-                       variable_names: Optional[Sequence[str]] = None, engine=None):
+                       variable_names: Optional[Sequence[str]] = None, engine=None, on_unsolvable: str = "raise"):
     """Forward integration of evaluate_lagrangian_on_test.py:59-68 with the accelerations solved from the Lagrangian:
     a = dd(theta_{i-1}, gamma_{i-1}, v_{i-1});  v_i = v_{i-1} + a dt;  q_i = q_{i-1} + v_{i-1} dt.
     The initial values may be arrays of equal length B: B independent rollouts in one launch.  Returns (theta, gamma,
@@ -256,6 +286,12 @@ def lagrangian_rollout(lagrangian: str, time, theta0, gamma0, vtheta0, vgamma0,
     from .engine import default_engine
     eng = engine or default_engine()
     el = euler_lagrange(lagrangian, variable_names)
+    if on_unsolvable not in ("raise", "zero"):
+        raise ValueError("on_unsolvable must be 'raise' or 'zero'")
+    if any(getattr(el, "vanishing", (False, False))) and on_unsolvable == "raise":
+        raise ExpressionError("the Euler-Lagrange equations of this Lagrangian cannot be solved for ddtheta / ddgamma: an acceleration "
+                              "coefficient vanishes (sp.solve returns []); on_unsolvable='zero' integrates with zero acceleration, as "
+                              "the reference's pipeline does after catching the IndexError (lagrangian_pipeline.py:150-153)")
     if el.acc_theta is None or el.acc_gamma is None:
         raise ExpressionError("the Euler-Lagrange equations of this Lagrangian cannot be solved for ddtheta / ddgamma separately "
                               "(vanishing or coupled acceleration terms): the reference's sp.solve(...)[0] path fails on it too")

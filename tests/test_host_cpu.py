@@ -301,7 +301,18 @@ def test_euler_lagrange_derivation_matches_the_reference_route():
     # lambdify over (theta, gamma, dtheta, dgamma) cannot evaluate -- reported as not isolable; so is a missing d^2 term
     el = rovmpc.euler_lagrange("0.5*x2**2 + 0.5*x3**2 + 0.3*x2*x3*cos(x0) - x0**2")
     assert el.acc_theta is None and el.acc_gamma is None and "x5" in el.eom_theta and "x4" in el.eom_gamma
-    assert rovmpc.euler_lagrange("x0*x2 + 0.5*x3**2").acc_theta is None
+    # a missing d^2 term: sp.solve returns [] and the reference's pipeline integrates with zero acceleration after catching the
+    # IndexError (lagrangian_pipeline.py:150-153) -- here: acceleration "0.0" with the fact recorded (lagrangian_rollout raises
+    # unless on_unsolvable="zero")
+    el = rovmpc.euler_lagrange("x0*x2 + 0.5*x3**2")
+    assert el.acc_theta == "0.0" and el.vanishing == (True, False)
+    # a cross coefficient that is zero only after like terms cancel does not couple the equations (sympy would cancel it)
+    el = rovmpc.euler_lagrange("0.5*x2**2 + 0.5*x3**2 + (x0 - x0)*x2*x3 - cos(x0)")
+    assert el.acc_theta is not None and el.acc_gamma is not None and el.vanishing == (False, False)
+    # d|u|/du is sign(u) with sign(0) = 0 (sympy), not u / |u|
+    from rovmpc.lagrangian import differentiate, _parse, _text
+    d = _text(differentiate(_parse("abs(x0)", None), "x0"))
+    assert _np_eval(d, np.array([[0.0, 0, 0, 0, 0, 0], [-2.0, 0, 0, 0, 0, 0], [3e-280, 0, 0, 0, 0, 0]])).tolist() == [0.0, -1.0, 1.0]
     # named variables, and what the grammar refuses
     el = rovmpc.euler_lagrange("0.5*dth**2 + 0.5*dga**2 - th*ga", variable_names=("th", "ga", "dth", "dga"))
     assert el.eom_theta == "x4 + x1" and el.acc_gamma == "-x0"
