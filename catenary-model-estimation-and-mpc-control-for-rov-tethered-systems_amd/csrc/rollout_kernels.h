@@ -44,8 +44,26 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 #ifndef ROVMPC_JIT_NSUB
 #define ROVMPC_JIT_NSUB 0
 #endif
+// Structure the code generator found in the loaded rows (rovmpc.hip::jit_source; generation-1 map only):
+//   ROVMPC_JIT_GI  dgamma/dt reads nothing but x15 / x17 (gamma and its delay slot): the gamma path is candidate-invariant, one
+//                  wave integrates it once per workgroup and tabulates what hangs on it, as for the compiled-in rows;
+//   ROVMPC_JIT_TS  dtheta/dt reads neither x14 nor x15 (no stage state): the four RK4 slopes of a step are f at the start row,
+//                  twice at the midpoint row and at the end row -- no stage loop, and the end row's slope is the next step's
+//                  start slope;
+//   ROVMPC_JIT_NGSUB  subexpressions of dtheta/dt that read x17 alone (jit_gsub): evaluated on the gamma wave per row.
+#ifndef ROVMPC_JIT_GI
+#define ROVMPC_JIT_GI 0
+#endif
+#ifndef ROVMPC_JIT_TS
+#define ROVMPC_JIT_TS 0
+#endif
+#ifndef ROVMPC_JIT_NGSUB
+#define ROVMPC_JIT_NGSUB 0
+#endif
+constexpr int JIT_GROW = 16;       // row stride of the gamma table of a ROVMPC_JIT_GI kernel: [0..5] as the compiled-in one, [8 + 3 k + {0, 1, 2}] = g_k at the step's start / midpoint / end row
+template <typename T> __device__ void jit_gsub(const T *x, T *g);
 template <typename T> __device__ void jit_exo(const T *x, T *e);
-template <typename T> __device__ T jit_f_theta(const T *x, const T *e);
+template <typename T> __device__ T jit_f_theta(const T *x, const T *e, const T *g);
 template <typename T> __device__ T jit_f_gamma(const T *x, const T *e);
 
 constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
@@ -418,7 +436,7 @@ __host__ __device__ inline int rollout_na(int model, int vt) {
 }
 constexpr int HDR = 48;            // header: flags (8 slots) + mean[18] + inv_scale[18] (+ pad)
 
-template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt, unsigned used = 0xffffffffu) {
+template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N, int CK, int model, int vt, unsigned used = 0xffffffffu, int jit_gi = 0) {
     size_t planes = 3 /*P*/ + 2 /*theta,gamma*/ + rollout_nx(model, vt, used) + rollout_na(model, vt);
     size_t e = HDR;
     e += planes * (size_t)(N + 1) * CK;              // node planes
@@ -427,6 +445,7 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
     e += (size_t)2 * CK * N;                         // warm start of the second catenary solve of a node (u, exp u)
     if (model == MODEL_INTERP) e += (size_t)(18 + ROVMPC_MAX_STACK) * CK;   // features + stack
     if (model == MODEL_BUILTIN) e += (size_t)8 * (N + 1);                    // candidate-invariant gamma table
+    if (model == MODEL_JIT && jit_gi) e += (size_t)JIT_GROW * (N + 1);       // the same of a loaded model with a candidate-invariant gamma path
     return e;
 }
 
@@ -512,7 +531,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // G_n is the candidate-invariant part of the RK4 sum of dtheta/dt (see theta_path).
     const int nintB = ((CK + 15) / 16) * 64;                 // theta waves of the compiled-in model
     const bool wideB = MODEL == MODEL_BUILTIN && NT >= nintB + 64;
-    const bool gwave = MODEL == MODEL_BUILTIN && (wideB ? (tid >= nintB && tid < nintB + 64) : tid < 64);
+    // (a loaded model whose gamma path is candidate-invariant -- ROVMPC_JIT_GI -- gets a gamma wave as well: the wave behind its
+    // single integrating wave)
+    constexpr bool JGI = MODEL == MODEL_JIT && ROVMPC_JIT_GI != 0;
+    constexpr int GROW = JGI ? JIT_GROW : 8;                 // row stride of the gamma table
+    const int nintG = JGI ? 64 : nintB;
+    const bool wideG = (MODEL == MODEL_BUILTIN || JGI) && NT >= nintG + 64;
+    const bool gwave = (MODEL == MODEL_BUILTIN || JGI) && (wideG ? (tid >= nintG && tid < nintG + 64) : tid < 64);
     auto gamma_chain = [&]() {
         const int lane = tid & 63;
         const int nsteps = (a.debug & 1) ? 0 : N;
@@ -522,22 +547,38 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // so the affine closed form of the step -- two FMAs -- does not hold 1e-9 beyond ~30 steps: measured),
         // carried by every lane, stored by lane 0.  One loop per mode: no selects on the chain.
         T ga = ga0, gam = gam0;
+        // dgamma/dt on (scaled x15, scaled x17): the compiled-in row, or the loaded one (which reads nothing else)
+        auto fgam = [&](T s15, T p17) -> T {
+            if (JGI) {
+                T x[18];
+#pragma unroll
+                for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
+                x[15] = s15; x[17] = p17;
+                T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
+                jit_exo<T>(x, e);                       // (subexpressions of constants only; the others are dead here)
+                return jit_f_gamma<T>(x, e);
+            }
+            return s15 - p17;
+        };
         auto run = [&](auto HOLD, auto EULER) {
             for (int n = 0; n < nsteps; ++n) {
                 const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;      // np.roll delay slot, simply.py:35-38
                 const T p17m = HOLD.value ? s17a : (s17a + s17b) / T(2);
                 const T p17e = HOLD.value ? s17a : s17b;
-                const T k1g = (ga - m15) * i15 - s17a;
+                const T k1g = fgam((ga - m15) * i15, s17a);
                 T gan;
                 if (EULER.value) {
                     gan = ga + k1g * hstep;                                     // main_fun.py:762
                 } else {
-                    const T k2g = ((ga + hh * k1g) - m15) * i15 - p17m;
-                    const T k3g = ((ga + hh * k2g) - m15) * i15 - p17m;
-                    const T k4g = ((ga + hstep * k3g) - m15) * i15 - p17e;
+                    const T k2g = fgam(((ga + hh * k1g) - m15) * i15, p17m);
+                    const T k3g = fgam(((ga + hh * k2g) - m15) * i15, p17m);
+                    const T k4g = fgam(((ga + hstep * k3g) - m15) * i15, p17e);
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);      // :66
+                    if (JGI && lane == 0) {      // gamma's stage states, for a dtheta/dt that reads them (slots 2..4 of the row)
+                        sG[GROW * n + 2] = ga + hh * k1g; sG[GROW * n + 3] = ga + hh * k2g; sG[GROW * n + 4] = ga + hstep * k3g;
+                    }
                 }
-                if (lane == 0) sG[8 * n + 5] = gan;
+                if (lane == 0) sG[GROW * n + 5] = gan;
                 gam = ga; ga = gan;
             }
         };
@@ -582,16 +623,48 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
         if (with_G) gamma_G(first, stride);
     };
+    // Loaded model with a candidate-invariant gamma path (ROVMPC_JIT_GI): what the integrating wave and the geometry read of it.
+    // Row n of the table: [0], [1] sincos(gamma_n) (n = 0..N); [5] gamma_{n+1} (the chain); [8 + 3 k + w] the x17-only
+    // subexpression k of dtheta/dt (jit_gsub) on the delay slot at the start (w = 0), midpoint (1) and end (2) row of step n.
+    auto gamma_table_jit = [&]() {
+        const int lane = tid & 63;
+        const int nsteps = (a.debug & 1) ? 0 : N;
+        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+        const T m17 = sMean[17], i17 = sInv[17];
+        constexpr int NG = ROVMPC_JIT_NGSUB;
+        const int n_sub = NG > 0 ? 3 * nsteps : 0;
+        for (int i = lane; i < n_sub + (nsteps > 0 ? N + 1 : 0); i += 64) {
+            if (i < n_sub) {
+                const int n = i / 3, w = i - 3 * n;
+                const T g_n = n == 0 ? ga0 : sG[GROW * (n - 1) + 5];
+                const T g_m = n == 0 ? gam0 : (n == 1 ? ga0 : sG[GROW * (n - 2) + 5]);
+                const T s17a = (g_m - m17) * i17, s17b = (g_n - m17) * i17;
+                T x[18];
+#pragma unroll
+                for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
+                x[17] = (hold || w == 0) ? s17a : (w == 1 ? (s17a + s17b) / T(2) : s17b);
+                T g[NG > 0 ? NG : 1];
+                jit_gsub<T>(x, g);
+#pragma unroll
+                for (int k = 0; k < NG; ++k) sG[GROW * n + 8 + 3 * k + w] = g[k];
+            } else {
+                const int n = i - n_sub;
+                T sv, cv;
+                m_sincos(n == 0 ? ga0 : sG[GROW * (n - 1) + 5], &sv, &cv);
+                sG[GROW * n] = sv; sG[GROW * n + 1] = cv;
+            }
+        }
+    };
     // sines shared by the whole workgroup: when they are more than one pass of the gamma wave (3 N + 2 > 64) and phase 2 is
     // bounded by that wave (C3, N = 50: chain 3.2 us + three passes 1.8 us against 1.3 us of phase 2a) the other waves, idle
     // at the barrier, take their share as soon as the chain is through (LDS flag): one pass instead of three
-    const bool share_sines = wideB && 3 * N + 2 > 64;
+    const bool share_sines = MODEL == MODEL_BUILTIN && wideB && 3 * N + 2 > 64;
     int *s_chain_done = s_best_c + 6;
 
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
     // (compiled-in model, wide workgroup: the gamma wave has nothing to fetch)
-    const int ltid = wideB ? (tid < nintB ? tid : tid - 64) : tid, LNT = wideB ? NT - 64 : NT;
-    if (!(wideB && gwave)) {
+    const int ltid = wideG ? (tid < nintG ? tid : tid - 64) : tid, LNT = wideG ? NT - 64 : NT;
+    if (!(wideG && gwave)) {
         const T *src = Ub + (size_t)k0 * N * 3;
         const int tot = nvalid * N * 3;
         constexpr int VW = 16 / sizeof(T);           // elements per 16-byte lane load
@@ -685,10 +758,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     if ((tid & 63) == 0) st_agent(a.seq_gamma, (unsigned long long)(a.step + 1));
                 }
             }
-            if ((tid & 63) == 0) sG[8 * N + 1] = ga0;           // phase 2b's gamma_0 (this wave alone knows it)
+            if (MODEL == MODEL_BUILTIN && (tid & 63) == 0) sG[8 * N + 1] = ga0;           // phase 2b's gamma_0 (this wave alone knows it)
         }
         RV_STAMP_W(9);
-        if (share_sines) { if ((tid & 63) == 0) __hip_atomic_store(s_chain_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        if (JGI) gamma_table_jit();
+        else if (share_sines) { if ((tid & 63) == 0) __hip_atomic_store(s_chain_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
         else gamma_sines(tid & 63, 64, true);
         RV_STAMP_W(10);
     }
@@ -788,7 +862,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     if (MODEL == MODEL_BUILTIN) {
         const int p2m = ((N + 1) * CK + LNT - 1) / LNT;          // nodes per thread
         const int c = ltid & ckm, n0 = (ltid >> cks) * p2m;
-        if (!(wideB && gwave) && !(a.debug & 4) && n0 <= N) {
+        if (!(wideG && gwave) && !(a.debug & 4) && n0 <= N) {
             T Px = P1x0, Py = P1y0, Pz = P1z0;
             const T *u = &sU[c * US];
             for (int j = 0; j < n0; ++j) {
@@ -805,7 +879,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // form above costs them 0.5 us at C2).  Full rounds take the far nodes in ascending order, the partial last round the
         // nodes next to the anchor (an item's cost grows with n).
         const int p2rem = (N + 1) % max(LNT >> cks, 1);
-        for (int i = ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
+        for (int i = (wideG && gwave) ? (N + 1) * CK : ltid; i < ((a.debug & 4) ? 0 : (N + 1) * CK); i += LNT) {
             const int q = i >> cks, c = i & ckm;
             const int n = q < N + 1 - p2rem ? p2rem + q : q - (N + 1 - p2rem);
             T Px = P1x0, Py = P1y0, Pz = P1z0;
@@ -897,6 +971,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             // sincos(gamma_{n+1}) is candidate-invariant: the gamma wave left it in its table (node N: row N, slots 2 / 3)
             const int gi = n + 1 < N ? 8 * (n + 1) : 8 * N + 2;
             sg = sG[gi]; cg = sG[gi + 1];
+        } else if (JGI) {
+            sg = sG[GROW * (n + 1)]; cg = sG[GROW * (n + 1) + 1];
         } else {
             trig4.sincos(ga, &sg, &cg);
         }
@@ -1170,7 +1246,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         }
                         T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
                         jit_exo<T>(x, e);
-                        dth = jit_f_theta<T>(x, e);
+                        dth = jit_f_theta<T>(x, e, (const T *)nullptr);
                         dga = jit_f_gamma<T>(x, e);
                         return;
                     }
@@ -1271,7 +1347,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         x[14] = x[15] = x[16] = x[17] = T(0);
                         T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
                         jit_exo<T>(x, e);
-                        ddth = jit_f_theta<T>(x, e);
+                        ddth = jit_f_theta<T>(x, e, (const T *)nullptr);
                         ddga = jit_f_gamma<T>(x, e);
                         return;
                     }
@@ -1431,6 +1507,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 jit_exo<T>(x, e);
             };
             exo_subs(xa, xb, 0, ea);
+            // ROVMPC_JIT_TS: the end row's slope of a step is the next step's start slope when the delay slots are interpolated
+            // (HOLD keeps the previous node's value through the step: its end row is not the next start row) and RK4 evaluates it
+            const bool carry_ok = ROVMPC_JIT_TS && !hold && !euler;
+            T kA_carry = T(0);
             auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
@@ -1444,7 +1524,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (!euler) exo_subs(A, B, 1, em);
                 const T s16a = (thm - m16) * i16, s16b = (th - m16) * i16;
                 const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;
-                auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga) {
+                // the x17-only subexpressions of dtheta/dt on this step's three rows, from the gamma wave's table
+                constexpr int NG = (ROVMPC_JIT_GI && ROVMPC_JIT_NGSUB > 0) ? ROVMPC_JIT_NGSUB : 1;
+                T gsa[NG], gsm[NG], gsb[NG];
+                if (ROVMPC_JIT_GI && ROVMPC_JIT_NGSUB > 0) {
+#pragma unroll
+                    for (int k = 0; k < NG; ++k) {
+                        gsa[k] = sG[GROW * n + 8 + 3 * k]; gsm[k] = sG[GROW * n + 8 + 3 * k + 1]; gsb[k] = sG[GROW * n + 8 + 3 * k + 2];
+                    }
+                }
+                // one evaluation of the pair at stage state (yth, yga) on the start (cfrac2 = 0), midpoint (1) or end (2) row
+                auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga, auto WANT_TH, auto WANT_GA) {
                     T p16, p17;
                     if (hold || cfrac2 == 0) { p16 = s16a; p17 = s17a; }
                     else if (cfrac2 == 2) { p16 = s16b; p17 = s17b; }
@@ -1452,6 +1542,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     T x[18];
                     fill_exo(x, A, B, cfrac2);
                     const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
+                    const T *g = cfrac2 == 0 ? gsa : (cfrac2 == 2 ? gsb : gsm);
                     if (gen2) {
                         // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
                         x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
@@ -1462,25 +1553,82 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     } else {
                         x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
                     }
-                    dth = jit_f_theta<T>(x, e);
-                    dga = jit_f_gamma<T>(x, e);
+                    if (WANT_TH.value) dth = jit_f_theta<T>(x, e, g);
+                    if (WANT_GA.value) dga = jit_f_gamma<T>(x, e);
                 };
-                T k1t, k1g;
-                stage(th, ga, 0, k1t, k1g);
+                constexpr BoolC<true> YES{};
+                constexpr BoolC<false> NO{};
                 T thn, gan;
+                if (ROVMPC_JIT_TS) {
+                    // dtheta/dt reads no stage state: its slopes are f on the start row, the midpoint row (twice) and the end row
+                    T dummy = T(0);
+                    T kat = kA_carry, kmt = T(0), kbt = T(0);
+                    if (!carry_ok || n == 0) stage(th, ga, 0, kat, dummy, YES, NO);
+                    if (!euler) stage(th, ga, 1, kmt, dummy, YES, NO);
+                    if (!euler || carry_ok) stage(th, ga, 2, kbt, dummy, YES, NO);
+                    kA_carry = kbt;
+                    thn = euler ? th + kat * hstep : th + h6 * (kat + T(2) * kmt + T(2) * kmt + kbt);    // :66 with k2 = k3
+                    if (ROVMPC_JIT_GI) {
+                        gan = sG[GROW * n + 5];                                  // the gamma wave's chain
+                    } else {
+                        // gamma's own stages, with theta's stage states known beforehand
+                        T k1g, k2g, k3g, k4g;
+                        stage(th, ga, 0, dummy, k1g, NO, YES);
+                        if (euler) {
+                            gan = ga + k1g * hstep;
+                        } else {
+                            stage(th + hh * kat, ga + hh * k1g, 1, dummy, k2g, NO, YES);
+                            stage(th + hh * kmt, ga + hh * k2g, 1, dummy, k3g, NO, YES);
+                            stage(th + hstep * kmt, ga + hstep * k3g, 2, dummy, k4g, NO, YES);
+                            gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
+                        }
+                    }
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);                    // A is dead from here on
+                } else if (ROVMPC_JIT_GI) {
+                    // gamma's path and stage states come from the gamma wave's table; dtheta/dt runs its stages on them
+                    T dummy = T(0), k1t, k2t, k3t, k4t;
+                    stage(th, ga, 0, k1t, dummy, YES, NO);
+                    if (euler) {
+                        thn = th + k1t * hstep;
+                    } else {
+                        stage(th + hh * k1t, sG[GROW * n + 2], 1, k2t, dummy, YES, NO);
+                        stage(th + hh * k2t, sG[GROW * n + 3], 1, k3t, dummy, YES, NO);
+                        stage(th + hstep * k3t, sG[GROW * n + 4], 2, k4t, dummy, YES, NO);
+                        thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);
+                    }
+                    gan = sG[GROW * n + 5];
+                    if (n + 1 < nsteps) fetch_rows(n + 2, A);
+                } else {
+                T k1t, k1g;
+                stage(th, ga, 0, k1t, k1g, YES, YES);
                 if (euler) {
                     thn = th + k1t * hstep;                                     // main_fun.py:761
                     gan = ga + k1g * hstep;
                     if (n + 1 < nsteps) fetch_rows(n + 2, A);
                 } else {
                     T k2t, k2g, k3t, k3g, k4t, k4g;
-                    stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g);
-                    stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g);
+                    stage(th + hh * k1t, ga + hh * k1g, 1, k2t, k2g, YES, YES);
+                    stage(th + hh * k2t, ga + hh * k2g, 1, k3t, k3g, YES, YES);
                     if (n + 1 < nsteps) fetch_rows(n + 2, A);                  // A is dead from here on
-                    stage(th + hstep * k3t, ga + hstep * k3g, 2, k4t, k4g);
+                    stage(th + hstep * k3t, ga + hstep * k3g, 2, k4t, k4g, YES, YES);
                     thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);    // :66
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);
                 }
+                }
+                if (ROVMPC_JIT_GI) {
+                    // sincos(gamma_{n+1}) is in the table; theta alone advances by angle addition
+                    if (need_trig && n + 1 < nsteps) {
+                        sg = sG[GROW * (n + 1)]; cg = sG[GROW * (n + 1) + 1];
+                        if (((n + 1) & 15) == 0) m_sincos(thn, &st, &ct);
+                        else {
+                            const T d = thn - th;
+                            T rs, rc;
+                            add_angle(st, ct, d, rs, rc);
+                            if (__any(!(m_abs(d) < T(0.0078125)))) { T fs, fc; m_sincos(thn, &fs, &fc); if (!(m_abs(d) < T(0.0078125))) { rs = fs; rc = fc; } }
+                            st = rs; ct = rc;
+                        }
+                    }
+                } else
                 if (need_trig && n + 1 < nsteps) {
                     if (((n + 1) & 15) == 0) { m_sincos(thn, &st, &ct); m_sincos(gan, &sg, &cg); }
                     else sincos_near2(thn, th, st, ct, st, ct, gan, ga, sg, cg, sg, cg);
@@ -1579,7 +1727,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
                     x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                     x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
-                    ddth = jit_f_theta<T>(x, e);
+                    ddth = jit_f_theta<T>(x, e, (const T *)nullptr);
                     ddga = jit_f_gamma<T>(x, e);
                 };
                 T a1t, a1g;

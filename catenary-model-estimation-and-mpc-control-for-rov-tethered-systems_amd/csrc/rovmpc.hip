@@ -33,6 +33,7 @@ struct rovmpc_handle {
     int model_kind = MODEL_INTERP;   // MODEL_BUILTIN | MODEL_INTERP | MODEL_JIT
     hipFunction_t jit_fn = nullptr;  // MODEL_JIT: kernel of the run-time specialised module
     hipFunction_t jit_fn_step = nullptr;   //            its pipelined closed-loop step entry
+    int jit_gi = 0, jit_ts = 0;            //            structure found in the rows (ROVMPC_JIT_GI / ROVMPC_JIT_TS of rollout_kernels.h)
     hipStream_t pipe_streams[2] = {nullptr, nullptr};     // pipelined closed loop: launches alternate between the two
     bool pipe_placed = false, pipe_stream_owned = false;  // [1] probed against the caller's stream; replaced by one of the handle's own
     std::string pipe_placement;
@@ -167,12 +168,12 @@ extern "C" const char *rovmpc_last_error(const rovmpc_handle *h) {
 
 extern "C" int32_t rovmpc_result_len(const rovmpc_handle *h) { return h ? 5 + 2 * (h->cfg.N + 1) : 0; }
 
-static size_t lds_need(const rovmpc_config *c, int ck, int model, unsigned used = 0xffffffffu) {
-    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, model, c->vt_mode, used) * sizeof(double)
-                                  : rollout_lds_elems<float>(c->N, ck, model, c->vt_mode, used) * sizeof(float);
+static size_t lds_need(const rovmpc_config *c, int ck, int model, unsigned used = 0xffffffffu, int jit_gi = 0) {
+    return c->dtype == ROVMPC_F64 ? rollout_lds_elems<double>(c->N, ck, model, c->vt_mode, used, jit_gi) * sizeof(double)
+                                  : rollout_lds_elems<float>(c->N, ck, model, c->vt_mode, used, jit_gi) * sizeof(float);
 }
 
-static int pick_ck(const rovmpc_config *c, int model, unsigned used, int n_cu) {
+static int pick_ck(const rovmpc_config *c, int model, unsigned used, int n_cu, int jit_gi = 0) {
     if (c->candidates_per_block > 0) return c->candidates_per_block;
     // 16 candidates x 4 role lanes fill one wave in the sequential phase of the compiled-in
     // model; shrink only to keep two workgroups per CU inside the 160 KiB of LDS
@@ -184,7 +185,7 @@ static int pick_ck(const rovmpc_config *c, int model, unsigned used, int n_cu) {
     // their integrating waves in each other's way: measured +25 % on the slower of the two); beyond that keep two per CU
     const bool one_per_cu = (c->K + ck - 1) / ck <= n_cu;
     const size_t cap = (ck > 16 || one_per_cu) ? 160 * 1024 : 80 * 1024;
-    while (ck > 1 && lds_need(c, ck, model, used) > cap) ck /= 2;
+    while (ck > 1 && lds_need(c, ck, model, used, jit_gi) > cap) ck /= 2;
     return ck;
 }
 
@@ -252,7 +253,7 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
         hipDeviceProp_t prop{};
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
     }
-    h->CK = pick_ck(cfg, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu, h->n_cu);
+    h->CK = pick_ck(cfg, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu, h->n_cu, h->jit_gi);
     // one thread per (candidate, horizon step) of the workgroup when that fits 512 threads, so
     // the per-node geometry phase is a single round
     int items = cfg->N * h->CK;
@@ -264,7 +265,7 @@ static const char *configure_geometry(rovmpc_handle *h, int model, bool strict =
     h->nblocks = (cfg->K + h->CK - 1) / h->CK;
     if (cfg->threads_per_block > 0) h->NT = cfg->threads_per_block;
     if (h->NT < 64 * ((h->CK + 15) / 16)) h->NT = 64 * ((h->CK + 15) / 16);
-    if (strict && lds_need(cfg, h->CK, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu) > 160 * 1024)
+    if (strict && lds_need(cfg, h->CK, model, model == MODEL_JIT ? jit_lds_planes(h->used_planes, cfg->vt_mode, cfg->feature_map) : 0xffffffffu, h->jit_gi) > 160 * 1024)
         return "rollout workgroup needs more than 160 KiB of LDS; lower candidates_per_block or N";
     return nullptr;
 }
@@ -457,20 +458,31 @@ static std::string fmt_const(double v) {
 // and referenced as e[k]; `a / D` with a stage-invariant D becomes a * e[k], e[k] = 1 / D (one more rounding, <= 1.5 ulp).
 // Both expressions share the list (identical subtrees get one entry); at most ROVMPC_MAX_SUBS of them, the rest stay inline.
 constexpr int ROVMPC_MAX_SUBS = 8;
+constexpr int ROVMPC_MAX_GSUBS = 2;         // x17-only subexpressions the gamma wave tabulates (rollout_kernels.h: JIT_GROW)
+// gsubs (optional): the same for subtrees of dtheta/dt that read the slots of `gmask` alone (the gamma delay slot x17 when the
+// gamma path is candidate-invariant): emitted as g[k], evaluated by the gamma wave once per row and workgroup.
 static std::string bytecode_to_cxx(const int32_t *code, int n, const double *consts, unsigned state_mask = 0xffffffffu,
-                                   std::vector<std::string> *subs = nullptr) {
-    struct Item { std::string text; bool exo; int heavy; bool leaf; };
+                                   std::vector<std::string> *subs = nullptr, std::vector<std::string> *gsubs = nullptr, unsigned gmask = 0) {
+    struct Item { std::string text; unsigned slots; int heavy; bool leaf; };
     std::vector<Item> st;
-    auto hoist = [&](Item &it) {            // replace a stage-invariant, expensive subtree by e[k]
-        if (!subs || !it.exo || it.heavy == 0) return;
+    auto is_exo = [&](const Item &it) { return (it.slots & state_mask) == 0; };
+    auto is_g = [&](const Item &it) { return gsubs && it.slots != 0 && (it.slots & ~gmask) == 0; };
+    auto hoist_into = [&](Item &it, std::vector<std::string> *list, const char *name, int cap) {
         int k = -1;
-        for (size_t q = 0; q < subs->size(); ++q) if ((*subs)[q] == it.text) k = (int)q;
+        for (size_t q = 0; q < list->size(); ++q) if ((*list)[q] == it.text) k = (int)q;
         if (k < 0) {
-            if ((int)subs->size() >= ROVMPC_MAX_SUBS) return;
-            subs->push_back(it.text); k = (int)subs->size() - 1;
+            if ((int)list->size() >= cap) return;
+            list->push_back(it.text); k = (int)list->size() - 1;
         }
-        it.text = "e[" + std::to_string(k) + "]"; it.heavy = 0; it.leaf = true;
+        it.text = std::string(name) + "[" + std::to_string(k) + "]"; it.heavy = 0; it.leaf = true;
     };
+    auto hoist = [&](Item &it) {            // replace a stage-invariant, expensive subtree by e[k] (or g[k])
+        if (it.heavy == 0) return;
+        if (subs && is_exo(it)) hoist_into(it, subs, "e", ROVMPC_MAX_SUBS);
+        else if (is_g(it)) hoist_into(it, gsubs, "g", ROVMPC_MAX_GSUBS);
+    };
+    // the class of a subtree: 0 = reads a slot outside both sets, 1 = stage-invariant (no state slot), 2 = gamma-delay-slot only
+    auto cls = [&](const Item &it) { return is_exo(it) ? 1 : (is_g(it) ? 2 : 0); };
     for (int pc = 0; pc < n; ++pc) {
         const int op = code[pc] & 0xff, arg = code[pc] >> 8;
         auto un = [&](const char *f, int cost) {
@@ -480,23 +492,27 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
         auto bin = [&](const char *pre, const char *mid, const char *post, int cost) {
             Item b = st.back(); st.pop_back();
             Item &a = st.back();
-            if (a.exo != b.exo) { hoist(a.exo ? a : b); }      // the invariant side ends here: it is maximal
+            // a side whose class the combination loses ends here: it is maximal (a constant-only side joins either class)
+            const bool a_const = a.slots == 0, b_const = b.slots == 0;
+            if (!a_const && !b_const && cls(a) != cls(b)) { hoist(a); hoist(b); }
+            else if (cls(a) == 0 && b_const && b.heavy) hoist(b);
+            else if (cls(b) == 0 && a_const && a.heavy) hoist(a);
             a.text = std::string(pre) + a.text + mid + b.text + post;
-            a.exo = a.exo && b.exo; a.heavy += b.heavy + cost; a.leaf = false;
+            a.slots |= b.slots; a.heavy += b.heavy + cost; a.leaf = false;
         };
         const size_t need = op <= ROVMPC_OP_PUSH_F ? 0 : ((op >= ROVMPC_OP_ADD && op <= ROVMPC_OP_DIV) || op == ROVMPC_OP_POW) ? 2 : 1;
         if (st.size() < need) return "m_nan<T>()";          // (validate_code has already checked the stack discipline)
         switch (op) {
-        case ROVMPC_OP_PUSH_C: st.push_back({fmt_const(consts[arg]), true, 0, true}); break;
-        case ROVMPC_OP_PUSH_F: st.push_back({"x[" + std::to_string(arg) + "]", arg < 32 && !((state_mask >> arg) & 1u), 0, true}); break;
+        case ROVMPC_OP_PUSH_C: st.push_back({fmt_const(consts[arg]), 0u, 0, true}); break;
+        case ROVMPC_OP_PUSH_F: st.push_back({"x[" + std::to_string(arg) + "]", arg < 32 ? (1u << arg) : 0x80000000u, 0, true}); break;
         case ROVMPC_OP_ADD: bin("(", " + ", ")", 0); break;
         case ROVMPC_OP_SUB: bin("(", " - ", ")", 0); break;
         case ROVMPC_OP_MUL: bin("(", " * ", ")", 0); break;
         case ROVMPC_OP_DIV: {
             Item &b = st.back(), &a = st[st.size() - 2];
             const bool b_const = b.leaf && b.text.compare(0, 2, "T(") == 0;
-            if (subs && b.exo && !a.exo && !b_const) {          // a / D, D stage-invariant: a * (1 / D), the reciprocal per row
-                Item r = {"m_divq(T(1), " + b.text + ")", true, b.heavy + 1, false};
+            if (subs && is_exo(b) && !is_exo(a) && !b_const) {          // a / D, D stage-invariant: a * (1 / D), the reciprocal per row
+                Item r = {"m_divq(T(1), " + b.text + ")", b.slots, b.heavy + 1, false};
                 hoist(r);
                 if (r.leaf) { b = r; bin("(", " * ", ")", 0); break; }
             }
@@ -523,6 +539,14 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
     if (st.empty()) return "m_nan<T>()";
     hoist(st.back());                                          // an expression that no stage state enters at all
     return st.back().text;
+}
+
+// slots a program reads (bit j = feature j)
+static unsigned program_slots(const int32_t *code, int n) {
+    unsigned m = 0;
+    for (int pc = 0; pc < n; ++pc)
+        if ((code[pc] & 0xff) == ROVMPC_OP_PUSH_F && (code[pc] >> 8) < 32) m |= 1u << (code[pc] >> 8);
+    return m;
 }
 
 struct JitModule { hipModule_t mod = nullptr; hipFunction_t fn = nullptr, fn_step = nullptr; };
@@ -571,19 +595,31 @@ static hipFunction_t jit_build(int device, const std::string &src, std::string &
     return m.fn;
 }
 
+// What the rows' slot-dependency sets allow (generation-1 map; ROVMPC_JIT_NO_STRUCT=1 switches it off): see rollout_kernels.h.
+static void jit_structure(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga, int *gi, int *ts) {
+    *gi = *ts = 0;
+    if (h->cfg.feature_map != ROVMPC_FEATURES_GEN1 || getenv("ROVMPC_JIT_NO_STRUCT")) return;
+    const unsigned dep_th = program_slots(code_th, n_th), dep_ga = program_slots(code_ga, n_ga);
+    if ((dep_ga & ~((1u << 15) | (1u << 17))) == 0) *gi = 1;        // dgamma/dt on (gamma, gamma_prev) alone
+    if ((dep_th & ((1u << 14) | (1u << 15))) == 0) *ts = 1;         // dtheta/dt blind to the stage state
+}
+
 static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
-                              const double *consts) {
+                              const double *consts, int gi, int ts) {
     const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
     // the slots a stage sets itself (everything else is a row of a node, or the midpoint of two)
     const unsigned state_mask = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 0xf000u        // theta, gamma, cos theta, sin gamma
                               : h->cfg.feature_map == ROVMPC_FEATURES_GEN3 ? 0x3c00fu       // theta, gamma, their rates (+ the unused tail)
                                                                            : 0x3c000u;      // x14..x17: state and delay slots
-    std::vector<std::string> subs;
-    const std::string f_th = bytecode_to_cxx(code_th, n_th, consts, state_mask, getenv("ROVMPC_JIT_NO_HOIST") ? nullptr : &subs);
-    const std::string f_ga = bytecode_to_cxx(code_ga, n_ga, consts, state_mask, getenv("ROVMPC_JIT_NO_HOIST") ? nullptr : &subs);
+    std::vector<std::string> subs, gsubs;
+    const bool hoist = !getenv("ROVMPC_JIT_NO_HOIST");
+    const std::string f_th = bytecode_to_cxx(code_th, n_th, consts, state_mask, hoist ? &subs : nullptr, (gi && hoist) ? &gsubs : nullptr, 1u << 17);
+    const std::string f_ga = bytecode_to_cxx(code_ga, n_ga, consts, state_mask, hoist ? &subs : nullptr);
     std::string s;
     s += "#define ROVMPC_JIT_FMAP " + std::to_string(h->cfg.feature_map) + "\n";
     s += "#define ROVMPC_JIT_NSUB " + std::to_string(subs.size()) + "\n";
+    s += "#define ROVMPC_JIT_GI " + std::to_string(gi) + "\n#define ROVMPC_JIT_TS " + std::to_string(ts) + "\n";
+    s += "#define ROVMPC_JIT_NGSUB " + std::to_string(gsubs.size()) + "\n";
     s += "#define ROVMPC_JIT_USED " + std::to_string(h->used_planes) + "u\n#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
     s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
     s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
@@ -591,8 +627,11 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     s += std::string("template <> __device__ void jit_exo<") + real + ">(const " + real + " *x, " + real + " *e) { typedef " + real + " T; (void)x; (void)e;";
     for (size_t k = 0; k < subs.size(); ++k) s += " e[" + std::to_string(k) + "] = " + subs[k] + ";";
     s += " }\n";
-    s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x, const " + real + " *e) { typedef " + real +
-         " T; (void)e; return " + f_th + "; }\n";
+    s += std::string("template <> __device__ void jit_gsub<") + real + ">(const " + real + " *x, " + real + " *g) { typedef " + real + " T; (void)x; (void)g;";
+    for (size_t k = 0; k < gsubs.size(); ++k) s += " g[" + std::to_string(k) + "] = " + gsubs[k] + ";";
+    s += " }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x, const " + real + " *e, const " + real +
+         " *g) { typedef " + real + " T; (void)e; (void)g; return " + f_th + "; }\n";
     s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e) { typedef " + real +
          " T; (void)e; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
@@ -744,13 +783,15 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     }
     h->builtin = same;
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
-    h->jit_fn = nullptr; h->jit_fn_step = nullptr;
+    h->jit_fn = nullptr; h->jit_fn_step = nullptr; h->jit_gi = 0; h->jit_ts = 0;
     h->err.clear();
     if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features <= 18) {
         std::string why;
-        const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts);
+        int gi = 0, ts = 0;
+        jit_structure(h, code_theta, n_code_theta, code_gamma, n_code_gamma, &gi, &ts);
+        const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts, gi, ts);
         hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_step);
-        if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; }
+        if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; h->jit_gi = gi; h->jit_ts = ts; }
         else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
     }
     if (const char *why = configure_geometry(h, h->model_kind)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
@@ -845,7 +886,7 @@ template <typename T> static hipError_t launch_rollout_t(const rovmpc_handle *h,
     a.result = d_result; a.k_offset = k_offset; a.slots = d_slots; a.rank = rank; a.world = world;
     const int vt = h->cfg.vt_mode;
     if (h->model_kind == MODEL_JIT) {
-        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+        const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map), h->jit_gi) * sizeof(T);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         size_t asz = sizeof(a);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
@@ -2120,7 +2161,7 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
         if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
     } else if (h->model_kind == MODEL_JIT) {
         if (!h->jit_fn_step) FAIL(h, ROVMPC_ERR_UNSUPPORTED, "the run-time specialised module has no pipelined entry");
-        const size_t lds = rollout_lds_elems<T>(h->cfg.N, g.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+        const size_t lds = rollout_lds_elems<T>(h->cfg.N, g.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map), h->jit_gi) * sizeof(T);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int per_cu = 0;
         if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->jit_fn_step, g.NT, lds) != hipSuccess) per_cu = 0;
@@ -2146,7 +2187,7 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
         const HandoffArgs &pi = p;
         hipError_t e;
         if (h->model_kind == MODEL_JIT) {
-            const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map)) * sizeof(T);
+            const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map), h->jit_gi) * sizeof(T);
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             struct { RolloutArgs<T> a; HandoffArgs p; } both{a, pi};
             size_t asz = sizeof(both);
