@@ -60,11 +60,14 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 #ifndef ROVMPC_JIT_NGSUB
 #define ROVMPC_JIT_NGSUB 0
 #endif
+#ifndef ROVMPC_JIT_PIN_TRIG
+#define ROVMPC_JIT_PIN_TRIG 0           // the generated expressions hold a sine: pin its coefficients for the integration loop
+#endif
 constexpr int JIT_GROW = 16;       // row stride of the gamma table of a ROVMPC_JIT_GI kernel: [0..5] as the compiled-in one, [8 + 3 k + {0, 1, 2}] = g_k at the step's start / midpoint / end row
-template <typename T> __device__ void jit_gsub(const T *x, T *g);
-template <typename T> __device__ void jit_exo(const T *x, T *e);
-template <typename T> __device__ T jit_f_theta(const T *x, const T *e, const T *g);
-template <typename T> __device__ T jit_f_gamma(const T *x, const T *e);
+template <typename T> __device__ void jit_gsub(const T *x, T *g, const Trig<T> &tg);
+template <typename T> __device__ void jit_exo(const T *x, T *e, const Trig<T> &tg);
+template <typename T> __device__ T jit_f_theta(const T *x, const T *e, const T *g, const Trig<T> &tg);
+template <typename T> __device__ T jit_f_gamma(const T *x, const T *e, const Trig<T> &tg);
 
 constexpr int NEXO = 14;           // exogenous feature slots x0..x13 (simply.py:41)
 constexpr int NAX  = 8;            // theta axis (x,y) + gamma axis (x,y,z) + unit_rel (x,y,z)
@@ -540,6 +543,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     const bool gwave = (MODEL == MODEL_BUILTIN || JGI) && (wideG ? (tid >= nintG && tid < nintG + 64) : tid < 64);
     auto gamma_chain = [&]() {
         const int lane = tid & 63;
+        const Trig<T> trigj(false);               // (loaded models: the context their generated expressions take)
         const int nsteps = (a.debug & 1) ? 0 : N;
         const T m15 = sMean[15], i15 = sInv[15], m17 = sMean[17], i17 = sInv[17];
         const T hstep = kk.h, hh = T(0.5) * hstep, h6 = hstep / T(6);
@@ -555,8 +559,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
                 x[15] = s15; x[17] = p17;
                 T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
-                jit_exo<T>(x, e);                       // (subexpressions of constants only; the others are dead here)
-                return jit_f_gamma<T>(x, e);
+                jit_exo<T>(x, e, trigj);                       // (subexpressions of constants only; the others are dead here)
+                return jit_f_gamma<T>(x, e, trigj);
             }
             return s15 - p17;
         };
@@ -628,6 +632,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // subexpression k of dtheta/dt (jit_gsub) on the delay slot at the start (w = 0), midpoint (1) and end (2) row of step n.
     auto gamma_table_jit = [&]() {
         const int lane = tid & 63;
+        const Trig<T> trigj(false);
         const int nsteps = (a.debug & 1) ? 0 : N;
         const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
         const T m17 = sMean[17], i17 = sInv[17];
@@ -644,7 +649,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
                 x[17] = (hold || w == 0) ? s17a : (w == 1 ? (s17a + s17b) / T(2) : s17b);
                 T g[NG > 0 ? NG : 1];
-                jit_gsub<T>(x, g);
+                jit_gsub<T>(x, g, trigj);
 #pragma unroll
                 for (int k = 0; k < NG; ++k) sG[GROW * n + 8 + 3 * k + w] = g[k];
             } else {
@@ -1168,6 +1173,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // bytecode model: CK lanes of wave 0 integrate; the other waves take phase 4a
         const int nint = 64;
         auto integrate = [&]() {
+            const Trig<T> trigj(false);
             if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
@@ -1245,9 +1251,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                             x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
                         }
                         T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
-                        jit_exo<T>(x, e);
-                        dth = jit_f_theta<T>(x, e, (const T *)nullptr);
-                        dga = jit_f_gamma<T>(x, e);
+                        jit_exo<T>(x, e, trigj);
+                        dth = jit_f_theta<T>(x, e, (const T *)nullptr, trigj);
+                        dga = jit_f_gamma<T>(x, e, trigj);
                         return;
                     }
                     for (int s = 0; s < NEXO; ++s) {
@@ -1293,6 +1299,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // the half stages, simulate_rk4_theta_gamma.py:62).  integrator EULER = the reference's explicit double Euler
         // (test_cluster.py:113-129).  State slots 14/15 carry (dtheta, dgamma) at node 0.
         auto integrate_dd = [&]() {
+            const Trig<T> trigj(false);
             const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
             if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
@@ -1346,9 +1353,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
                         x[14] = x[15] = x[16] = x[17] = T(0);
                         T e[ROVMPC_JIT_NSUB > 0 ? ROVMPC_JIT_NSUB : 1];
-                        jit_exo<T>(x, e);
-                        ddth = jit_f_theta<T>(x, e, (const T *)nullptr);
-                        ddga = jit_f_gamma<T>(x, e);
+                        jit_exo<T>(x, e, trigj);
+                        ddth = jit_f_theta<T>(x, e, (const T *)nullptr, trigj);
+                        ddga = jit_f_gamma<T>(x, e, trigj);
                         return;
                     }
                     for (int p = 0; p < 10; ++p) {
@@ -1425,6 +1432,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         };
         constexpr unsigned VELMASK = 0x21f8u;       // planes 3..8 and 13: velocity, acceleration, angle_proj
         auto integrate_jit = [&]() {
+            // the sines of the generated expressions run on the chain: their coefficients are pinned in registers once (a 64-bit
+            // literal costs two moves per use)
+            const Trig<T> trigj(ROVMPC_JIT_PIN_TRIG != 0);
             if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
                 if (a.from_ring) { th0 = ring_get(0); ga0 = ring_get(1); thm0 = ring_get(2); gam0 = ring_get(3); }
@@ -1465,9 +1475,21 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (compose_rows)
                 vel_slots(xa, Vx, Vy, Vz, A0x, A0y, A0z, RV_PL(sA, 5, 0, c), RV_PL(sA, 6, 0, c), RV_PL(sA, 7, 0, c));
             // operands of a step: rotation axes and control of node n, unit vector of node n + 1
-            struct Ops { T ktx, kty, kgx, kgy, kgz, u0, u1, u2, ux, uy, uz; };
+            // (ROVMPC_JIT_GI: + what the step reads of the gamma wave's table -- gamma_{n+1}, its sincos, gamma's stage states, the
+            // x17-only subexpressions on the three rows -- fetched a step ahead like the rest: a table read inside the step is an
+            // LDS round trip on the chain)
+            constexpr int NGT = (ROVMPC_JIT_GI && ROVMPC_JIT_NGSUB > 0) ? ROVMPC_JIT_NGSUB : 1;
+            struct Ops { T ktx, kty, kgx, kgy, kgz, u0, u1, u2, ux, uy, uz; T gnext, sgn, cgn, gst2, gst3, gst4, gs[3 * NGT]; };
             Ops opA = {}, opB = {};
             auto fetch_ops = [&](int n, Ops &o) {
+                if (ROVMPC_JIT_GI) {
+                    o.gnext = sG[GROW * n + 5]; o.sgn = sG[GROW * (n + 1)]; o.cgn = sG[GROW * (n + 1) + 1];
+                    if (!ROVMPC_JIT_TS) { o.gst2 = sG[GROW * n + 2]; o.gst3 = sG[GROW * n + 3]; o.gst4 = sG[GROW * n + 4]; }
+                    if (ROVMPC_JIT_NGSUB > 0) {
+#pragma unroll
+                        for (int k = 0; k < 3 * NGT; ++k) o.gs[k] = sG[GROW * n + 8 + k];
+                    }
+                }
                 if (!compose_rows) return;
                 o.ktx = RV_PL(sA, 0, n, c); o.kty = RV_PL(sA, 1, n, c);
                 o.kgx = RV_PL(sA, 2, n, c); o.kgy = RV_PL(sA, 3, n, c); o.kgz = RV_PL(sA, 4, n, c);
@@ -1504,7 +1526,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 #pragma unroll
                 for (int sl = 0; sl < 18; ++sl) x[sl] = T(0);
                 fill_exo(x, A, B, cfrac2);
-                jit_exo<T>(x, e);
+                jit_exo<T>(x, e, trigj);
             };
             exo_subs(xa, xb, 0, ea);
             // ROVMPC_JIT_TS: the end row's slope of a step is the next step's start slope when the delay slots are interpolated
@@ -1529,9 +1551,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 T gsa[NG], gsm[NG], gsb[NG];
                 if (ROVMPC_JIT_GI && ROVMPC_JIT_NGSUB > 0) {
 #pragma unroll
-                    for (int k = 0; k < NG; ++k) {
-                        gsa[k] = sG[GROW * n + 8 + 3 * k]; gsm[k] = sG[GROW * n + 8 + 3 * k + 1]; gsb[k] = sG[GROW * n + 8 + 3 * k + 2];
-                    }
+                    for (int k = 0; k < NG; ++k) { gsa[k] = o.gs[3 * k]; gsm[k] = o.gs[3 * k + 1]; gsb[k] = o.gs[3 * k + 2]; }
                 }
                 // one evaluation of the pair at stage state (yth, yga) on the start (cfrac2 = 0), midpoint (1) or end (2) row
                 auto stage = [&](T yth, T yga, int cfrac2, T &dth, T &dga, auto WANT_TH, auto WANT_GA) {
@@ -1553,8 +1573,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     } else {
                         x[14] = (yth - m14) * i14; x[15] = (yga - m15) * i15; x[16] = p16; x[17] = p17;
                     }
-                    if (WANT_TH.value) dth = jit_f_theta<T>(x, e, g);
-                    if (WANT_GA.value) dga = jit_f_gamma<T>(x, e);
+                    if (WANT_TH.value) dth = jit_f_theta<T>(x, e, g, trigj);
+                    if (WANT_GA.value) dga = jit_f_gamma<T>(x, e, trigj);
                 };
                 constexpr BoolC<true> YES{};
                 constexpr BoolC<false> NO{};
@@ -1569,7 +1589,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     kA_carry = kbt;
                     thn = euler ? th + kat * hstep : th + h6 * (kat + T(2) * kmt + T(2) * kmt + kbt);    // :66 with k2 = k3
                     if (ROVMPC_JIT_GI) {
-                        gan = sG[GROW * n + 5];                                  // the gamma wave's chain
+                        gan = o.gnext;                                           // the gamma wave's chain
                     } else {
                         // gamma's own stages, with theta's stage states known beforehand
                         T k1g, k2g, k3g, k4g;
@@ -1591,12 +1611,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     if (euler) {
                         thn = th + k1t * hstep;
                     } else {
-                        stage(th + hh * k1t, sG[GROW * n + 2], 1, k2t, dummy, YES, NO);
-                        stage(th + hh * k2t, sG[GROW * n + 3], 1, k3t, dummy, YES, NO);
-                        stage(th + hstep * k3t, sG[GROW * n + 4], 2, k4t, dummy, YES, NO);
+                        stage(th + hh * k1t, o.gst2, 1, k2t, dummy, YES, NO);
+                        stage(th + hh * k2t, o.gst3, 1, k3t, dummy, YES, NO);
+                        stage(th + hstep * k3t, o.gst4, 2, k4t, dummy, YES, NO);
                         thn = th + h6 * (k1t + T(2) * k2t + T(2) * k3t + k4t);
                     }
-                    gan = sG[GROW * n + 5];
+                    gan = o.gnext;
                     if (n + 1 < nsteps) fetch_rows(n + 2, A);
                 } else {
                 T k1t, k1g;
@@ -1618,7 +1638,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (ROVMPC_JIT_GI) {
                     // sincos(gamma_{n+1}) is in the table; theta alone advances by angle addition
                     if (need_trig && n + 1 < nsteps) {
-                        sg = sG[GROW * (n + 1)]; cg = sG[GROW * (n + 1) + 1];
+                        sg = o.sgn; cg = o.cgn;
                         if (((n + 1) & 15) == 0) m_sincos(thn, &st, &ct);
                         else {
                             const T d = thn - th;
@@ -1645,6 +1665,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
         auto integrate_dd_jit = [&]() {
+            const Trig<T> trigj(false);
             const T vs_reg = kk.vs;       // a register for the loop (the constants live in global memory: one load per trip otherwise)
             if (HANDOFF && a.wait_theta) {        // (models without the gamma shortcut take all four from the end-of-step record)
                 ring_wait(a.seq_theta);
@@ -1700,7 +1721,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 T x[18];
                 x[0] = x[1] = x[2] = x[3] = T(0);
                 fill_exo(x, A, B, cfrac2);
-                jit_exo<T>(x, e);
+                jit_exo<T>(x, e, trigj);
             };
             bool ea_ready = false;
             auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
@@ -1727,8 +1748,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
                     x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
                     x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
-                    ddth = jit_f_theta<T>(x, e, (const T *)nullptr);
-                    ddga = jit_f_gamma<T>(x, e);
+                    ddth = jit_f_theta<T>(x, e, (const T *)nullptr, trigj);
+                    ddga = jit_f_gamma<T>(x, e, trigj);
                 };
                 T a1t, a1g;
                 stage(y0, y1, y2, y3, 0, a1t, a1g);

@@ -521,7 +521,7 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
         }
         case ROVMPC_OP_POW: bin("m_pow(", ", ", ")", 1); break;
         case ROVMPC_OP_NEG: un("-", 0); break;
-        case ROVMPC_OP_SIN: un("m_sin", 1); break;
+        case ROVMPC_OP_SIN: un("tg.sin", 1); break;
         case ROVMPC_OP_COS: un("m_cos", 1); break;
         case ROVMPC_OP_TANH: un("m_tanh", 1); break;
         case ROVMPC_OP_ABS: un("m_abs", 0); break;
@@ -602,6 +602,7 @@ static void jit_structure(const rovmpc_handle *h, const int32_t *code_th, int n_
     const unsigned dep_th = program_slots(code_th, n_th), dep_ga = program_slots(code_ga, n_ga);
     if ((dep_ga & ~((1u << 15) | (1u << 17))) == 0) *gi = 1;        // dgamma/dt on (gamma, gamma_prev) alone
     if ((dep_th & ((1u << 14) | (1u << 15))) == 0) *ts = 1;         // dtheta/dt blind to the stage state
+    if (*ts && !*gi) *ts = 0;       // (measured: with gamma's stages still on the chain the split evaluations cost rows 5 / 9 0.4 us)
 }
 
 static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
@@ -620,20 +621,26 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     s += "#define ROVMPC_JIT_NSUB " + std::to_string(subs.size()) + "\n";
     s += "#define ROVMPC_JIT_GI " + std::to_string(gi) + "\n#define ROVMPC_JIT_TS " + std::to_string(ts) + "\n";
     s += "#define ROVMPC_JIT_NGSUB " + std::to_string(gsubs.size()) + "\n";
+    {
+        bool has_sin = false;
+        for (int pc = 0; pc < n_th; ++pc) has_sin = has_sin || (code_th[pc] & 0xff) == ROVMPC_OP_SIN;
+        for (int pc = 0; pc < n_ga; ++pc) has_sin = has_sin || (code_ga[pc] & 0xff) == ROVMPC_OP_SIN;
+        s += std::string("#define ROVMPC_JIT_PIN_TRIG ") + (has_sin ? "1" : "0") + "\n";
+    }
     s += "#define ROVMPC_JIT_USED " + std::to_string(h->used_planes) + "u\n#include \"rollout_kernels.h\"\nnamespace rovmpc {\n";
     s += "template <typename T> RV_DEV T rv_sq(T a) { return a * a; }\n";
     s += "template <typename T> RV_DEV T rv_powi(T b, int e) { int ae = e < 0 ? -e : e; T r = T(1); "
          "while (ae) { if (ae & 1) r *= b; b *= b; ae >>= 1; } return e < 0 ? T(1) / r : r; }\n";
-    s += std::string("template <> __device__ void jit_exo<") + real + ">(const " + real + " *x, " + real + " *e) { typedef " + real + " T; (void)x; (void)e;";
+    s += std::string("template <> __device__ void jit_exo<") + real + ">(const " + real + " *x, " + real + " *e, const Trig<" + real + "> &tg) { typedef " + real + " T; (void)x; (void)e; (void)tg;";
     for (size_t k = 0; k < subs.size(); ++k) s += " e[" + std::to_string(k) + "] = " + subs[k] + ";";
     s += " }\n";
-    s += std::string("template <> __device__ void jit_gsub<") + real + ">(const " + real + " *x, " + real + " *g) { typedef " + real + " T; (void)x; (void)g;";
+    s += std::string("template <> __device__ void jit_gsub<") + real + ">(const " + real + " *x, " + real + " *g, const Trig<" + real + "> &tg) { typedef " + real + " T; (void)x; (void)g; (void)tg;";
     for (size_t k = 0; k < gsubs.size(); ++k) s += " g[" + std::to_string(k) + "] = " + gsubs[k] + ";";
     s += " }\n";
     s += std::string("template <> __device__ ") + real + " jit_f_theta<" + real + ">(const " + real + " *x, const " + real + " *e, const " + real +
-         " *g) { typedef " + real + " T; (void)e; (void)g; return " + f_th + "; }\n";
-    s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e) { typedef " + real +
-         " T; (void)e; return " + f_ga + "; }\n";
+         " *g, const Trig<" + real + "> &tg) { typedef " + real + " T; (void)e; (void)g; (void)tg; return " + f_th + "; }\n";
+    s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e, const Trig<" + real + "> &tg) { typedef " + real +
+         " T; (void)e; (void)tg; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
          "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
