@@ -57,6 +57,7 @@ _SIGNATURES = {
     "rovmpc_set_model": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32]),
     "rovmpc_set_rotation_table": (C.c_int, [_P, _P]),
     "rovmpc_model_path": (C.c_int32, [_P]),
+    "rovmpc_model_structure": (C.c_int32, [_P]),
     "rovmpc_step": (C.c_int, [_P, C.POINTER(State), _P, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "rovmpc_rollout_costs": (C.c_int, [_P, C.POINTER(State), _P, _P, _P]),
     "rovmpc_mpc_step_sampled": (C.c_int, [_P, C.POINTER(State), C.c_uint64, C.c_uint64, _P, _P, C.c_int32, _P]),

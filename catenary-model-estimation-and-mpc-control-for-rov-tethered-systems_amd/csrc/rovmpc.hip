@@ -807,6 +807,7 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
 }
 
 extern "C" int32_t rovmpc_model_path(const rovmpc_handle *h) { return h ? h->model_kind : -1; }
+extern "C" int32_t rovmpc_model_structure(const rovmpc_handle *h) { return (h && h->model_kind == MODEL_JIT) ? (h->jit_gi | (h->jit_ts << 1)) : 0; }
 
 extern "C" int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R) {
     if (!h) return ROVMPC_ERR_INVALID;

@@ -190,6 +190,13 @@ class Engine:
         """'builtin' (compiled-in reference rows), 'interpreter' or 'jit' (hiprtc-specialised)."""
         return ("builtin", "interpreter", "jit")[int(self.lib.rovmpc_model_path(self._h))]
 
+    @property
+    def model_structure(self) -> set:
+        """What the code generator found in the loaded rows: {"gamma_invariant"} when dgamma/dt reads only (gamma, gamma_prev)
+        -- the gamma path is then integrated once per workgroup --, {"theta_stage_free"} when dtheta/dt reads no stage state."""
+        b = int(self.lib.rovmpc_model_structure(self._h))
+        return {n for k, n in ((1, "gamma_invariant"), (2, "theta_stage_free")) if b & k}
+
     def set_rotation_table(self, R):
         R = np.ascontiguousarray(R, dtype=np.float64)
         if R.shape != (self.cfg.N, 3, 3):

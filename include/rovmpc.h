@@ -164,6 +164,12 @@ int rovmpc_set_rotation_table(rovmpc_handle *h, const double *R);
  * the bytecode at rovmpc_set_model (falls back to 1 if hiprtc is unavailable; the reason is then
  * in rovmpc_last_error). */
 int32_t rovmpc_model_path(const rovmpc_handle *h);
+/* Structure the code generator found in a hiprtc-specialised model's rows, from their slot-dependency sets (0 otherwise):
+ * bit 0: dgamma/dt reads nothing but x15 / x17 (gamma, gamma_prev) -- the gamma path is the same for every candidate and is
+ *        integrated once per workgroup on a wave of its own, as for the reference's chosen rows;
+ * bit 1: dtheta/dt reads neither x14 nor x15 -- its four RK4 slopes need no stage loop (used together with bit 0).
+ * Generation-1 feature map only; environment ROVMPC_JIT_NO_STRUCT=1 switches the analysis off. */
+int32_t rovmpc_model_structure(const rovmpc_handle *h);
 
 /* ---- the hot path ---------------------------------------------------------------------
  * One MPC step: roll every candidate control sequence U[K][N][3] over the horizon

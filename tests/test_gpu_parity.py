@@ -842,6 +842,57 @@ def test_builtin_substitution_is_structural(rv):
         assert e.model_path == "jit"
 
 
+def test_code_generator_finds_the_structure_of_loaded_rows(rv, orc):
+    """What the compiled-in kernel exploits by hand -- gamma's path is candidate-invariant, dtheta/dt needs no stage loop -- the
+    code generator reads off the rows' slot-dependency sets (rovmpc_model_structure) and builds into the hiprtc kernel.  Each
+    combination against the oracle: both properties (the reference rows through hiprtc, rows 9 / 3), gamma-invariance only
+    (dtheta/dt row 7 reads the stage's gamma), stage-freedom only (rows 5 / 9: dgamma/dt reads the velocity slot), neither;
+    RK4 with interpolated and held delay slots, Euler; every velocity-transform mode; fp32; and with the analysis switched off."""
+    m = rv.default_model()
+    cases = [(13, 3, {"gamma_invariant", "theta_stage_free"}), (9, 3, {"gamma_invariant", "theta_stage_free"}),
+             (7, 3, {"gamma_invariant"}), (5, 9, set()), (7, 9, set()), (16, 5, {"gamma_invariant"})]
+    N, K = 20, 192
+    state, U = rv.synthetic_problem(K, N, seed=11)
+    for ct, cg, want in cases:
+        model = rv.default_model(ct, cg)
+        for vt_mode, prev_mode, integrator in [(1, 0, 0), (1, 1, 0), (1, 0, 1), (0, 0, 0), (2, 0, 0)]:
+            cfg = rv.MPCConfig(N=N, K=K, vt_mode=vt_mode, prev_mode=prev_mode, integrator=integrator, no_builtin=True)
+            R = rand_rtab(N) if vt_mode == 2 else None
+            with rv.Engine(cfg, model) as e:
+                if R is not None:
+                    e.set_rotation_table(R)
+                assert e.model_path == "jit" and e.model_structure == want, (ct, cg, e.model_structure)
+                J, traj = e.rollout_costs(state, U, return_traj=True)
+            Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U, R)
+            np.testing.assert_allclose(J, Jo, rtol=1e-8, err_msg=str((ct, cg, vt_mode, prev_mode, integrator)))
+            np.testing.assert_allclose(traj, trajo, rtol=1e-8, atol=1e-12)
+    # the model with property (i) only, at the C2 size, picks the oracle's candidate
+    model = rv.default_model(7, 3)
+    state, U = rv.synthetic_problem(4096, 20, seed=12)
+    cfg = rv.MPCConfig(N=20, K=4096)
+    with rv.Engine(cfg, model) as e:
+        assert e.model_structure == {"gamma_invariant"}
+        res = e.step(state, U)
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
+    assert res.index == int(np.argmin(Jo)) and res.cost == pytest.approx(Jo[res.index], rel=1e-9)
+    # fp32 and the switch
+    cfg = rv.MPCConfig(N=N, K=K, dtype="f32", no_builtin=True)
+    state, U = rv.synthetic_problem(K, N, seed=11, dtype=np.float32)
+    with rv.Engine(cfg, m) as e:
+        assert e.model_structure == {"gamma_invariant", "theta_stage_free"}
+        J32 = e.rollout_costs(state, U)
+    Jo, _, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, m), orc.MPCState.from_array(state), U.astype(np.float64))
+    np.testing.assert_allclose(J32, Jo, rtol=2e-4)
+    os.environ["ROVMPC_JIT_NO_STRUCT"] = "1"
+    try:
+        with rv.Engine(rv.MPCConfig(N=N, K=K, no_builtin=True), m) as e:
+            assert e.model_path == "jit" and e.model_structure == set()
+            Jg = e.rollout_costs(state.astype(np.float64), U.astype(np.float64))
+    finally:
+        del os.environ["ROVMPC_JIT_NO_STRUCT"]
+    np.testing.assert_allclose(Jg, Jo, rtol=1e-8)
+
+
 @pytest.mark.parametrize("B,K,N,dtype", [(8, 4096, 20, "f64"), (3, 67, 7, "f64"), (5, 1024, 20, "f32"), (64, 256, 20, "f64")])
 def test_batched_problems_equal_single_launches(rv, orc, B, K, N, dtype):
     """rovmpc_step_batch_device: B independent problems (own state, own candidates) in one launch.  Every problem's
