@@ -175,7 +175,7 @@ RV_DEV T interp_eval(const int32_t *__restrict__ code, int n, const T *__restric
         case ROVMPC_OP_ADD: top = stack[(sp - 2) * sstride] + top; --sp; break;
         case ROVMPC_OP_SUB: top = stack[(sp - 2) * sstride] - top; --sp; break;
         case ROVMPC_OP_MUL: top = stack[(sp - 2) * sstride] * top; --sp; break;
-        case ROVMPC_OP_DIV: top = m_divq(stack[(sp - 2) * sstride], top); --sp; break;
+        case ROVMPC_OP_DIV: top = m_divx(stack[(sp - 2) * sstride], top); --sp; break;
         case ROVMPC_OP_POW: top = m_pow(stack[(sp - 2) * sstride], top); --sp; break;
         case ROVMPC_OP_NEG: top = -top; break;
         case ROVMPC_OP_SIN: top = m_sin(top); break;

@@ -512,11 +512,11 @@ static std::string bytecode_to_cxx(const int32_t *code, int n, const double *con
             Item &b = st.back(), &a = st[st.size() - 2];
             const bool b_const = b.leaf && b.text.compare(0, 2, "T(") == 0;
             if (subs && is_exo(b) && !is_exo(a) && !b_const) {          // a / D, D stage-invariant: a * (1 / D), the reciprocal per row
-                Item r = {"m_divq(T(1), " + b.text + ")", b.slots, b.heavy + 1, false};
+                Item r = {"m_divx(T(1), " + b.text + ")", b.slots, b.heavy + 1, false};
                 hoist(r);
                 if (r.leaf) { b = r; bin("(", " * ", ")", 0); break; }
             }
-            bin("m_divq(", ", ", ")", 1);
+            bin("m_divx(", ", ", ")", 1);
             break;
         }
         case ROVMPC_OP_POW: bin("m_pow(", ", ", ")", 1); break;

@@ -124,6 +124,16 @@ def test_expression_division_keeps_numpy_special_cases(rv):
     assert np.array_equal(got[:n][~np.isnan(want[:n])], want[:n][~np.isnan(want[:n])])          # +-inf, +-0 exactly
     assert np.array_equal(np.signbit(got[:n][want[:n] == 0]), np.signbit(want[:n][want[:n] == 0]))
     np.testing.assert_allclose(got[n:], want[n:], rtol=4e-16, atol=0)
+    # operands whose reciprocal or quotient leaves the exponent range take the IEEE sequence (m_divx): generation-2 features are
+    # unscaled, nothing bounds them -- finite quotients stay finite, overflow is inf, underflow is a (sub)normal or zero
+    ext = [(1e300, 1e-300), (1e-300, 1e300), (3.0, 1e-310), (1e308, 1e308), (2e-308, 4.0), (1e200, 1e-200), (-7e305, 1e-10),
+           (1e-320, 1e-320), (5e150, 2e160), (1.0, 1e308), (1e308, 0.5)]
+    X2 = np.zeros((len(ext), 18))
+    X2[:, 0] = [a for a, _ in ext]; X2[:, 1] = [b for _, b in ext]
+    got2 = rv.SymbolicRegressor("x0 / x1").predict(X2)
+    with np.errstate(all="ignore"):
+        want2 = X2[:, 0] / X2[:, 1]
+    np.testing.assert_allclose(got2, want2, rtol=4e-16, atol=0)
 
 
 def test_solve_catenary_and_tension(rv, golden_dir):
