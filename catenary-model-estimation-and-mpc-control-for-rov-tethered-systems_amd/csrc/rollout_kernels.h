@@ -929,6 +929,21 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         }
         __syncthreads();
     }
+    // Loaded model with a candidate-invariant gamma path, composed velocity transform: as above, the first half of the transform
+    // w = R_gamma(-gamma_n) u_n hangs on the table alone and is finished here for every (node, candidate), in parallel, instead
+    // of on the integrating lane's chain (planes 5..7 carry w: they hold the unit vector only for a model that reads
+    // angle_proj, which keeps the rotation on the chain)
+    const bool jgi_w = JGI && VT == ROVMPC_VT_COMPOSE && (used & 0x21f8u) != 0 && !uses(13);
+    if (jgi_w) {
+        for (int i = tid; i < ((a.debug & 4) ? 0 : N * CK); i += NT) {
+            const int n = i >> cks, c = i & ckm;
+            const V3<T> kg = {RV_PL(sA, 2, n, c), RV_PL(sA, 3, n, c), RV_PL(sA, 4, n, c)};
+            const T *u = &sU[c * US + n * 3];
+            const V3<T> w = rodrigues_unit<T>({u[0], u[1], u[2]}, kg, -sG[GROW * n], sG[GROW * n + 1]);
+            RV_PL(sA, 5, n, c) = w.x; RV_PL(sA, 6, n, c) = w.y; RV_PL(sA, 7, n, c) = w.z;
+        }
+        __syncthreads();
+    }
 
     RV_STAMP(3);
     // ---- phase 3: closed-loop integration of (theta, gamma), with the state-independent half of
@@ -1492,9 +1507,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 }
                 if (!compose_rows) return;
                 o.ktx = RV_PL(sA, 0, n, c); o.kty = RV_PL(sA, 1, n, c);
-                o.kgx = RV_PL(sA, 2, n, c); o.kgy = RV_PL(sA, 3, n, c); o.kgz = RV_PL(sA, 4, n, c);
-                const T *u = &sU[c * US + n * 3];
-                o.u0 = u[0]; o.u1 = u[1]; o.u2 = u[2];
+                if (jgi_w) {                       // (u0..u2 carry w = R_gamma(-gamma_n) u_n, finished before the integration)
+                    o.u0 = RV_PL(sA, 5, n, c); o.u1 = RV_PL(sA, 6, n, c); o.u2 = RV_PL(sA, 7, n, c);
+                } else {
+                    o.kgx = RV_PL(sA, 2, n, c); o.kgy = RV_PL(sA, 3, n, c); o.kgz = RV_PL(sA, 4, n, c);
+                    const T *u = &sU[c * US + n * 3];
+                    o.u0 = u[0]; o.u1 = u[1]; o.u2 = u[2];
+                }
                 if (uses(13)) { o.ux = RV_PL(sA, 5, n + 1, c); o.uy = RV_PL(sA, 6, n + 1, c); o.uz = RV_PL(sA, 7, n + 1, c); }
             };
             auto fetch_rows = [&](int node, T *x) {
@@ -1537,7 +1556,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
-                    V3<T> v = rodrigues_unit<T>({o.u0, o.u1, o.u2}, kg, -sg, cg);
+                    V3<T> v = {o.u0, o.u1, o.u2};
+                    if (!jgi_w) v = rodrigues_unit<T>(v, kg, -sg, cg);
                     v = rodrigues_flat<T>(v, kt.x, kt.y, st, ct);
                     vel_slots(B, v.x, v.y, v.z, (v.x - Vx) * inv_hstep, (v.y - Vy) * inv_hstep, (v.z - Vz) * inv_hstep, o.ux, o.uy, o.uz);
                     Vx = v.x; Vy = v.y; Vz = v.z;
