@@ -648,9 +648,9 @@ def main():
                                "kernel_event_pair_min_us": kev_min_ms * 1e3 if kev_min_ms else None,
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "binding_bound": "fp64-valu issue / dependent-chain latency (see valu_f64); HBM is the bound BASELINE.json "
-                                                "asks to be reported, not the one that can limit this kernel: at ~1.5 kFLOP of fp64 per "
-                                                "24.4 algorithmic bytes even 100 % of the 78.6 TFLOP/s fp64 vector peak moves 78.6e12 / 1.5e3 "
-                                                "x 24.4 B = 1.3 TB/s = 16 % of HBM peak, so BASELINE's 40 % HBM target is out of reach by "
+                                                "asks to be reported, not the one that can limit this kernel: at 1 354 FLOP of fp64 per "
+                                                "24.4 algorithmic bytes (PMC) even 100 % of the 78.6 TFLOP/s fp64 vector peak moves 78.6e12 / 1354 "
+                                                "x 24.4 B = 1.42 TB/s = 18 % of HBM peak, so BASELINE's 40 % HBM target is out of reach by "
                                                 "arithmetic; the figures to drive are valu_f64.frac and the chain latency"}
             if (args.N, args.K, args.dtype, world) == (20, 4096, "f64", 1) and args.model == "default" and args.debug_flags == 0:
                 bench_extras.attach_pmc(out["roofline"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.json"), sha,
