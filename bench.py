@@ -131,7 +131,9 @@ def launch_ranks(args, argv):
     # the library's own RCCL path has never run at world > 1 (RCCL refuses two ranks on the one GPU of the build box):
     # it gets a bounded first attempt; if it dies OR does not finish, its whole process group is killed and the run is
     # repeated once on torch.distributed's collective, with the reason carried into the JSON line -- never a silent switch
-    t_first = min(args.launch_timeout, 300.0) if native else args.launch_timeout
+    # (two native modes are checked in-run, each cut short after --native-check-timeout seconds; the timed passes and the
+    # sharded closed loop follow)
+    t_first = min(args.launch_timeout, 2.0 * args.native_check_timeout + 240.0) if native else args.launch_timeout
     t0 = time.time()
     rc, line, out = _run_ranks(argv, args.gpus, t_first)
     if (rc != 0 or line is None) and native:

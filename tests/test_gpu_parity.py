@@ -1196,6 +1196,11 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(rv):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_agree"] is True and d["config"]["K_global"] == 2048
+    # BASELINE config 5 in its sharded form rides on the same line: the closed loop over the sharded step, every rank ending
+    # with the same records
+    cl = d["closed_loop"]
+    assert cl["n_gpus"] == 2 and cl["ranks_agree"] is True and cl["steps"] >= 100 and cl["us_per_step"] > 0 and cl["all_costs_finite"]
+    assert d["config"]["value_is_fallback"] is True and "strict_bracket" in d          # gloo: not the library's own RCCL path
     # the same 2 x 1024 candidates un-sharded on one handle: rank r's last batch is pool (steps - 1) % 8 of seed 20250523 + 1000 r + p
     pidx = (30 - 1) % 8
     state, _ = rv.synthetic_problem(1, 20)
