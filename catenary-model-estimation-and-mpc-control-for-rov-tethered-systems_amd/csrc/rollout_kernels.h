@@ -150,6 +150,11 @@ template <typename T> struct RolloutArgs {
     double *samp_best;            // [N][3]: this step's winner's sequence
     double *samp_blk_u;           // [nblocks][3 N]: every workgroup's best candidate's controls, handed over like its trajectory
     double samp_state[ROVMPC_STATE_LEN];
+    // Long horizons: the gamma table of the launch, shared between workgroups (null: none).  Workgroup 0 stores its finished
+    // table here (write-through) and tags it with the launch epoch; a workgroup that finds the tag when it starts -- the later
+    // rounds of a multi-round grid -- loads the table instead of integrating gamma again.  Nobody waits for anybody.
+    T *gtab;                      // [8 (N + 1)]
+    unsigned long long *gtab_tag;
 };
 
 // ---- learned dynamics ---------------------------------------------------------------------
@@ -232,6 +237,8 @@ RV_DEV void publish_best(unsigned long long *granules, int nblocks, unsigned epo
     st_agent(granules + 2 * (size_t)nblocks + blockIdx.x, tag | lane);
 }
 RV_DEV double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RV_DEV void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RV_DEV long long ld_agent(const long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One workgroup: lexicographic (cost, index) minimum over the per-block bests, then the
@@ -455,7 +462,10 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 // LEAN: the plain single-problem step (rovmpc_step_device and the host-pointer entry points): one problem, no slot image,
 // no hand-off flags, no host mirror, no plant update -- those branches are compiled out (measured on one box: the full
 // kernel is 0.3 us slower per C2 step than the round-1 kernel, which had none of them).
-template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false>
+// LONGH: the long-horizon instance (3 N + 2 > 64, compiled-in model, plain launches): shared gamma sines, the gamma table
+// shared between workgroups, geometry waves chasing the theta wave.  A separate instantiation, so that none of that code sits
+// in the instruction stream of the C2-sized kernels (their layout is touchy: +0.15 us at C2 with the code merely present).
+template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false, bool LONGH = false>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
@@ -663,7 +673,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // sines shared by the whole workgroup: when they are more than one pass of the gamma wave (3 N + 2 > 64) and phase 2 is
     // bounded by that wave (C3, N = 50: chain 3.2 us + three passes 1.8 us against 1.3 us of phase 2a) the other waves, idle
     // at the barrier, take their share as soon as the chain is through (LDS flag): one pass instead of three
-    const bool share_sines = MODEL == MODEL_BUILTIN && wideB && 3 * N + 2 > 64;
+    const bool share_sines = LONGH && MODEL == MODEL_BUILTIN && wideB && 3 * N + 2 > 64;
     int *s_chain_done = s_best_c + 6;
 
     // ---- phase 0: candidate controls -> LDS, coalesced ------------------------------------
@@ -749,6 +759,16 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     if (gwave) {
         RV_STAMP_W(8);
         if (HANDOFF && a.from_ring) { ring_wait(a.seq_gamma); ga0 = ring_get(1); gam0 = ring_get(3); }
+        // (long horizons, plain launches: a later round's workgroup finds the launch's gamma table published -- see gtab)
+        bool have_gtab = false;
+        if (!HANDOFF && !SAMPLE && MODEL == MODEL_BUILTIN && share_sines && a.gtab) {
+            const int got = (tid & 63) == 0 ? (int)(ld_agent(a.gtab_tag) == (unsigned long long)a.epoch) : 0;
+            have_gtab = __builtin_amdgcn_readfirstlane(got) != 0;
+        }
+        if (have_gtab) {
+            for (int i = tid & 63; i < 8 * (N + 1); i += 64) sG[i] = ld_agent(&a.gtab[i]);
+            if ((tid & 63) == 0) __hip_atomic_store(s_chain_done, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
         gamma_chain();
         if (HANDOFF) {
             if (a.from_ring || a.plant_feedback) {
@@ -769,6 +789,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         if (JGI) gamma_table_jit();
         else if (share_sines) { if ((tid & 63) == 0) __hip_atomic_store(s_chain_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
         else gamma_sines(tid & 63, 64, true);
+        }
         RV_STAMP_W(10);
     }
     // One thread takes `p2m` CONSECUTIVE nodes of one candidate: the position of its first node is the n-term sum
@@ -897,13 +918,14 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     }
     RV_STAMP(12);
     if (MODEL == MODEL_BUILTIN && share_sines) {
-        if (!gwave) while (__hip_atomic_load(s_chain_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
-        gamma_sines(tid, NT, false);
+        while (__hip_atomic_load(s_chain_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
+        if (__hip_atomic_load(s_chain_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1) gamma_sines(tid, NT, false);   // (2: the table was loaded whole)
     }
     __syncthreads();
     RV_STAMP(13);
+    const bool gtab_loaded = MODEL == MODEL_BUILTIN && share_sines && *s_chain_done == 2;
     if (MODEL == MODEL_BUILTIN) {
-        if (share_sines) gamma_G(tid, NT);           // (its reads are the shared sines; the theta chain reads it behind the next barrier)
+        if (share_sines && !gtab_loaded) gamma_G(tid, NT);           // (its reads are the shared sines; the theta chain reads it behind the next barrier)
         // ---- phase 2b: what hangs on gamma_n alone, for every (node, candidate): the gamma plane and the
         // first half of the velocity transform ------------------------------------------------------------
         // v_cat = R_theta(+theta_n) R_gamma(-gamma_n) u_n about the cable axes of node n (R @ v of
@@ -928,6 +950,13 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (!Trig<T>::bounded((m_abs(Ap) + m_abs(Bp)) + m_abs(Cp))) s_prog[0] = 1;
         }
         __syncthreads();
+        // workgroup 0 publishes its finished gamma table for the later rounds of the grid (write-through stores by one wave,
+        // drained, then the epoch tag: G16 form R1 with sc1 on both sides, as the epilogue's trajectories)
+        if (!HANDOFF && !SAMPLE && share_sines && a.gtab && !gtab_loaded && blockIdx.x == 0 && gwave) {
+            for (int i = tid & 63; i < 8 * (N + 1); i += 64) st_agent(&a.gtab[i], sG[i]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((tid & 63) == 0) st_agent(a.gtab_tag, (unsigned long long)a.epoch);
+        }
     }
     // Loaded model with a candidate-invariant gamma path, composed velocity transform: as above, the first half of the transform
     // w = R_gamma(-gamma_n) u_n hangs on the table alone and is finished here for every (node, candidate), in parallel, instead
@@ -1021,7 +1050,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // the last nodes' batch is left (C3, N = 50: two rounds = 3.7 us after the join -> one batch).  With a single round left
     // (C2, the throughput geometries) the chase gains nothing -- that round runs on every SIMD after the join, a chased batch
     // on one -- and the extra waves slow the integrating one (measured in round 1): those keep the early batch only.
-    const bool chase = MODEL == MODEL_BUILTIN && CK <= 16 && wideB && N * CK - early > NT;
+    const bool chase = LONGH && MODEL == MODEL_BUILTIN && CK <= 16 && wideB && N * CK - early > NT;
     // the integrating wave reports its progress only as far as somebody waits for it (the nodes of the early batch)
     const int prog_until = chase ? N : (early > 0 ? (early + CK - 1) / CK : 0);
     if (MODEL == MODEL_BUILTIN) {
@@ -1956,6 +1985,18 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_long(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, false, false, true>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_long_lean(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true, false, true>(a);
 }
 
 template <typename T, int MODEL, int VT>

@@ -62,6 +62,7 @@ struct rovmpc_handle {
     unsigned long long *d_granules = nullptr;  // [3][max_blocks] tagged hand-off granules
     unsigned *epoch_ctr = nullptr;            // launches issued (host counter; tag of the next launch = ++*epoch_ctr, never 0)
     unsigned long long *d_stamps = nullptr;   // diagnostic library only
+    void *d_gtab = nullptr;                   // shared gamma table of a launch (long horizons) + its epoch tag behind it
     const unsigned long long *arg_flag_consumed = nullptr;   // hand-off flags of the step being enqueued (native collective)
     unsigned long long *arg_flag_rolled = nullptr;
     unsigned long long arg_consumed_need = 0, arg_rolled_seq = 0;
@@ -383,6 +384,8 @@ extern "C" int rovmpc_create(const rovmpc_config *cfg, rovmpc_handle **out) {
     CR(hipMalloc((void **)&h->d_granules, (size_t)GRAN * max_blocks * sizeof(unsigned long long)));
     CR(hipMemset(h->d_granules, 0, (size_t)GRAN * max_blocks * sizeof(unsigned long long)));
     h->epoch_ctr = new unsigned(0);
+    CR(hipMalloc(&h->d_gtab, (size_t)8 * (cfg->N + 1) * 8 + 64));
+    CR(hipMemset(h->d_gtab, 0, (size_t)8 * (cfg->N + 1) * 8 + 64));
     CR(hipHostMalloc((void **)&h->h_err, 64, hipHostMallocMapped));
     *h->h_err = 0;
     CR(hipHostGetDevicePointer((void **)&h->d_err, h->h_err, 0));
@@ -405,7 +408,7 @@ extern "C" void rovmpc_destroy(rovmpc_handle *h) {
     for (auto &e : h->ev) (void)hipEventDestroy(e);
     void *ptrs[] = {h->d_U, h->d_J, h->d_traj_all, h->d_state, h->d_blk_traj,
                     h->d_result, h->d_code_th, h->d_code_ga, h->d_consts, h->d_consts64, h->d_Rtab, h->d_k, h->d_stamps,
-                    h->d_granules, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj, h->d_best, h->d_blk_u};
+                    h->d_granules, h->d_gtab, h->d_Jb, h->d_blk_trajb, h->d_granulesb, h->d_step_seq, h->d_Us[0], h->d_Us[1], h->d_cl_granules, h->d_cl_blk_traj, h->d_best, h->d_blk_u};
     for (auto &ev : h->pipe_ev) if (ev) (void)hipEventDestroy(ev);
     if (h->pipe_stream_owned && h->pipe_streams[1]) (void)hipStreamDestroy(h->pipe_streams[1]);
     if (h->h_record) (void)hipHostFree(h->h_record);
@@ -856,6 +859,10 @@ template <typename T> static void fill_args(const rovmpc_handle *h, RolloutArgs<
     a.slot_bad = h->arg_slot_bad; a.err = h->d_err; a.inject = h->arg_inject;
     a.handoff_ticks = (unsigned long long)(h->handoff_timeout_ms * 1e5);      // 100 MHz clock
     a.stamps = h->d_stamps;
+    // (single-problem launches only: a batch has a gamma path per problem)
+    static const bool no_gtab = getenv("ROVMPC_NO_GTAB") != nullptr;          // (diagnosis: every workgroup integrates gamma itself)
+    a.gtab = (B == 1 && !no_gtab) ? (T *)h->d_gtab : nullptr;
+    a.gtab_tag = B == 1 ? (unsigned long long *)((char *)h->d_gtab + (size_t)8 * (c.N + 1) * 8) : nullptr;
 }
 
 template <typename T, int MODEL, int VT>
@@ -865,7 +872,10 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, in
     const bool lean = MODEL == MODEL_BUILTIN && B == 1 && !a.slots && !a.flag_consumed && !a.flag_rolled && !a.result_host &&
                       !a.done_flag && !a.plant_next;
     auto kern = rollout_kernel<T, MODEL, VT>;
-    if constexpr (MODEL == MODEL_BUILTIN) { if (lean) kern = rollout_kernel_lean<T, MODEL, VT>; }     // (no lean instance of the interpreter kernel)
+    if constexpr (MODEL == MODEL_BUILTIN) {
+        if (3 * a.N + 2 > 64) kern = lean ? rollout_kernel_long_lean<T, MODEL, VT> : rollout_kernel_long<T, MODEL, VT>;      // long horizons: see rollout_body, LONGH
+        else if (lean) kern = rollout_kernel_lean<T, MODEL, VT>;             // (no lean instance of the interpreter kernel)
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

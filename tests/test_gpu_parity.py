@@ -572,6 +572,31 @@ def test_rollout_c3_fp32(rv, orc):
     assert r64.index == k
 
 
+def test_long_horizon_multi_round_grid_shares_the_gamma_table(rv, orc):
+    """N = 50, K = 16384 (config 3's size) in fp64: the grid runs in two rounds, the second round's workgroups load the gamma
+    table workgroup 0 published instead of integrating gamma again, the geometry waves chase the theta wave and the sines are
+    shared between waves -- all of it must leave the costs where the oracle has them, and repeated launches (fresh epochs,
+    another state in between) must reproduce themselves bit for bit."""
+    import torch
+    N, K = 50, 16384
+    cfg = rv.MPCConfig(N=N, K=K)
+    state, U = rv.synthetic_problem(K, N, seed=21)
+    state2 = state.copy(); state2[13] += 0.01; state2[15] -= 0.005           # another gamma path
+    with rv.Engine(cfg) as e:
+        J1 = e.rollout_costs(state, U)
+        J2 = e.rollout_costs(state2, U)
+        J1b = e.rollout_costs(state, U)
+        r = e.step(state, U)
+    assert np.array_equal(J1, J1b) and not np.array_equal(J1, J2)
+    om = oracle_model(orc, rv.default_model())
+    for st_, J in ((state, J1), (state2, J2)):
+        Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), om, orc.MPCState.from_array(st_), U)
+        np.testing.assert_allclose(J, Jo, rtol=1e-9)
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), om, orc.MPCState.from_array(state), U)
+    assert r.index == int(np.argmin(Jo))
+    np.testing.assert_allclose(r.traj, trajo[r.index], rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("K,N,ck", [(1, 1, 0), (67, 7, 16), (130, 3, 64), (5, 50, 4), (1000, 2, 0)])
 def test_ragged_and_tiny_shapes(rv, orc, K, N, ck):
     cfg = rv.MPCConfig(N=N, K=K, candidates_per_block=ck, n_shape_pts=5)
