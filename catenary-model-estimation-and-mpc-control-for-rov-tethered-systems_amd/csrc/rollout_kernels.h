@@ -319,7 +319,8 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
         }
         __syncthreads();
     }
-    if (!LEAN && a.ring && a.publish && tid < 64) {
+    // (sharded closed loop: the next step's theta is the GLOBAL winner's -- select_kernel hands it over behind the all-reduce)
+    if (!LEAN && a.ring && a.publish && !slots && tid < 64) {
         // closed loop, GPU-side hand-off: the next step's (theta0, gamma0, theta_prev, gamma_prev) = nodes 1 and 0 of the
         // winner, before anything else -- the record below is off the loop's critical path
         if (a.plant_feedback && tid < 4) st_agent(&a.ring[(int)((a.step + 1) & 3) * 4 + tid], ld_agent(&bt[tid < 2 ? 2 + tid : tid - 2]));
@@ -384,7 +385,7 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
     }
     // Closed loop on one GPU: the plant update of the next step (plant_update_kernel's rule) rides on this
     // workgroup -- every other workgroup has finished, nobody reads the state any more.
-    if (!LEAN && a.plant_next && tid < 16) {
+    if (!LEAN && a.plant_next && !(a.ring && slots) && tid < 16) {
         const double *plant_next = a.plant_next;
         double *plant_state = a.plant_state;
         if (!a.plant_feedback) {
@@ -2058,7 +2059,8 @@ closed_loop_step_kernel(const RolloutArgs<T> a, const HandoffArgs p) {
 // (cost, global index) minimum and decode it.
 __global__ void __launch_bounds__(64)
 select_kernel(const long long *slots, int world, int R, double *result, unsigned long long *flag_consumed = nullptr,
-              unsigned long long consumed_seq = 0, const unsigned long long *slot_bad = nullptr, int inject = 0) {
+              unsigned long long consumed_seq = 0, const unsigned long long *slot_bad = nullptr, int inject = 0,
+              double *ring = nullptr, unsigned long long *seq_theta = nullptr, long long step_next = 0) {
     __shared__ int s_r;
     if (threadIdx.x == 0) {
         double Jd = __builtin_inf(); double kd = __builtin_inf(); int rb = 0;
@@ -2074,6 +2076,16 @@ select_kernel(const long long *slots, int world, int R, double *result, unsigned
     // a hand-off of this use timed out (the row is not this step's): the record says so with a NaN cost
     const bool bad = slot_bad && ld_agent(slot_bad) == consumed_seq;
     for (int i = threadIdx.x; i < R; i += blockDim.x) result[i] = (bad && i == 0) ? __builtin_nan("") : ordered_val(slots[(size_t)rb * R + i]);
+    // Sharded closed loop with the state handed over on the GPU: the rollout of step `step_next` is already launched and its
+    // theta waves wait for this -- (theta, gamma) of its start = first predicted node of the GLOBAL winner, its delay slots =
+    // what this step started from (record: [J, k, u(3), th0, ga0, th1, ga1, ...]); then the sequence word.
+    if (ring && threadIdx.x == 0) {
+        double *r4 = ring + (int)(step_next & 3) * 4;
+        st_agent(&r4[0], ordered_val(slots[(size_t)rb * R + 7])); st_agent(&r4[1], ordered_val(slots[(size_t)rb * R + 8]));
+        st_agent(&r4[2], ordered_val(slots[(size_t)rb * R + 5])); st_agent(&r4[3], ordered_val(slots[(size_t)rb * R + 6]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(seq_theta, (unsigned long long)step_next);
+    }
     if (flag_consumed && !(inject & 2)) {    // every read of the slot buffer is done: it may be rewritten
         __syncthreads();
         if (threadIdx.x == 0) st_agent(flag_consumed, consumed_seq);
@@ -2095,6 +2107,21 @@ wait_rolled_kernel(const unsigned long long *flag_rolled, unsigned long long seq
     }
     raise_error(err, ERR_WAIT_ROLLED);
     st_agent(slot_bad, seq);
+}
+
+// State the closed loop with GPU-side hand-off leaves behind when the records, not the state buffer, carried it from step to
+// step: the state step T - 1 started from (rows: [T][16]; records: [T][R]).
+__global__ void __launch_bounds__(64)
+final_state_kernel(double *state, const double *rows, const double *records, long long T, int R, int feedback) {
+    const int t = threadIdx.x;
+    if (t >= 16) return;
+    const double *row = rows + (size_t)(T - 1) * 16;
+    double v = row[t];
+    if (feedback && T >= 2 && t >= 12) {
+        const double *rec = records + (size_t)(T - 2) * R;
+        v = t == 12 ? rec[7] : t == 13 ? rec[8] : t == 14 ? rec[5] : rec[6];
+    }
+    state[t] = v;
 }
 
 // Plant update of the closed-loop driver (one tiny workgroup): exogenous slots from the measured

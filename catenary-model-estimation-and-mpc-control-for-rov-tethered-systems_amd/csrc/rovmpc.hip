@@ -118,7 +118,8 @@ struct rovmpc_handle {
     bool slot_used[NSLOT] = {};
     // the collective is enqueued by a worker thread so its host cost (ncclAllReduce is ~20 us of
     // host time per call) overlaps the enqueue of the next rollout
-    struct CommJob { int p; double *d_result; unsigned long long use; int c; int inject; };
+    struct CommJob { int p; double *d_result; unsigned long long use; int c; int inject;
+                     double *ring; unsigned long long *seq_theta; long long step_next; };     // (closed loop: the select hands theta over)
     unsigned long long comm_rr = 0;       // steps issued: communicator of a step = comm_rr % ncomm (same on every rank)
     std::thread comm_thread;
     std::mutex comm_mu;
@@ -1759,7 +1760,8 @@ static void comm_worker(rovmpc_handle *h) {
         }
         if (err.empty()) {
             hipLaunchKernelGGL(select_kernel, dim3(1), dim3(64), 0, cs, (const long long *)h->d_slots[p],
-                               h->comm_world, (int)R, job.d_result, f_consumed, job.use, (const unsigned long long *)f_bad, job.inject);
+                               h->comm_world, (int)R, job.d_result, f_consumed, job.use, (const unsigned long long *)f_bad, job.inject,
+                               job.ring, job.seq_theta, job.step_next);
             e = hipGetLastError();
             if (e != hipSuccess) err = std::string("select kernel: ") + hipGetErrorString(e);
         }
@@ -2004,7 +2006,7 @@ extern "C" int rovmpc_step_device_allreduce(rovmpc_handle *h, const double *d_st
     if (rc) return rc;
     {
         std::lock_guard<std::mutex> lk(h->comm_mu);
-        h->comm_q.push_back({p, d_result, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm), inject});
+        h->comm_q.push_back({p, d_result, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm), inject, nullptr, nullptr, 0});
         ++h->comm_submitted[p];
     }
     h->comm_cv.notify_all();
@@ -2222,6 +2224,86 @@ static int closed_loop_pipelined_t(rovmpc_handle *h, const double *d_exo, int64_
     return ROVMPC_OK;
 }
 
+// ---- sharded closed loop with the state handed over on the GPU ----------------------------------------------------------
+// BASELINE config 5 as it is asked (every step the candidate-sharded one), model feedback: step g + 1's rollout is launched
+// right behind step g's on the caller's stream -- no join, no plant-update kernel, no event on that stream -- and waits ON THE
+// GPU for the state: gamma early from its own rank's sweeper (gamma's path is candidate-invariant, hence the same on every
+// rank), theta from the select kernel that follows step g's all-reduce on the collective stream (the GLOBAL winner's first
+// node).  Its controls load, positions, gamma table and first velocity-transform half run meanwhile, so a step costs
+// rollout + max(0, all-reduce + select - prologue) instead of rollout + all-reduce + select + join + update
+// (world 1: 47.5 -> ~20 us).  Compiled-in and hiprtc models; records are the join-based loop's bit for bit.
+template <typename T>
+static int closed_loop_sharded_handoff_t(rovmpc_handle *h, const double *d_exo, int64_t T_steps, double *d_state, const void *d_pools,
+                                         int32_t n_pools, int64_t k_offset, double *d_results, hipStream_t s) {
+    const Geo g = launch_geometry(h, 1);
+    const int vt = h->cfg.vt_mode;
+    const size_t R = rovmpc_result_len(h);
+    if (!h->comm_placed) {
+        int rc = place_comm_streams(h, s);
+        if (rc) return rc;
+    }
+    HandoffArgs p;
+    int rcw = closed_loop_workspace(h, p, s);
+    if (rcw) return rcw;
+    p.T = T_steps; p.exo = d_exo;
+    const size_t pool_bytes = (size_t)h->cfg.K * h->cfg.N * 3 * sizeof(T);
+    RolloutArgs<T> a;
+    for (int64_t i = 0; i < T_steps; ++i) {
+        const int sp = h->comm_flip;
+        h->comm_flip = (h->comm_flip + 1) % rovmpc_handle::NSLOT;
+        if (h->slot_used[sp]) {
+            int rc = comm_wait_enqueued(h, sp);
+            if (rc) return rc;
+        }
+        h->slot_used[sp] = true;
+        const unsigned long long use = ++h->slot_uses[sp];
+        h->arg_flag_consumed = h->d_flags + rovmpc_handle::NSLOT + sp; h->arg_consumed_need = use - 1;
+        h->arg_flag_rolled = h->d_flags + sp; h->arg_rolled_seq = use;
+        h->arg_slot_bad = h->d_flags + 2 * rovmpc_handle::NSLOT + sp;
+        int inject = 0;
+        if (h->inject_skip_rolled > 0) { --h->inject_skip_rolled; inject |= 1; }
+        if (h->inject_skip_consumed > 0) { --h->inject_skip_consumed; inject |= 2; }
+        h->arg_inject = inject;
+        h->plant_feedback = 1;
+        fill_args<T>(h, a, d_state, (const char *)d_pools + (size_t)(i % n_pools) * pool_bytes, nullptr, g, 1);   // one epoch per step
+        h->plant_feedback = 0;
+        h->arg_flag_consumed = nullptr; h->arg_flag_rolled = nullptr; h->arg_slot_bad = nullptr; h->arg_inject = 0;
+        a.result = h->d_result; a.k_offset = k_offset; a.slots = h->d_slots[sp]; a.rank = h->comm_rank; a.world = h->comm_world;
+        p.step = i;
+        hipError_t e;
+        int capacity = 0;
+        if (h->model_kind == MODEL_JIT) {
+            const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_JIT, vt, jit_lds_planes(h->used_planes, vt, h->cfg.feature_map), h->jit_gi) * sizeof(T);
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)h->jit_fn_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            struct { RolloutArgs<T> a; HandoffArgs p; } both{a, p};
+            size_t asz = sizeof(both);
+            void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            e = hipModuleLaunchKernel(h->jit_fn_step, a.nblocks, 1, 1, a.NT, 1, 1, (unsigned)lds, s, nullptr, extra);
+        } else {
+            if (i == 0) {      // (dynamic LDS attribute of the step kernel)
+                e = vt == 0 ? launch_step<T, 0>(h, a, p, s, true, &capacity) : vt == 1 ? launch_step<T, 1>(h, a, p, s, true, &capacity)
+                                                                              : launch_step<T, 2>(h, a, p, s, true, &capacity);
+                if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "occupancy query failed: %s", hipGetErrorString(e));
+            }
+            e = vt == 0 ? launch_step<T, 0>(h, a, p, s, false, &capacity) : vt == 1 ? launch_step<T, 1>(h, a, p, s, false, &capacity)
+                                                                          : launch_step<T, 2>(h, a, p, s, false, &capacity);
+        }
+        if (e != hipSuccess) FAIL(h, ROVMPC_ERR_HIP, "sharded closed-loop launch failed: %s", hipGetErrorString(e));
+        {
+            std::lock_guard<std::mutex> lk(h->comm_mu);
+            h->comm_q.push_back({sp, d_results + (size_t)i * R, use, (int)(h->comm_rr++ % (unsigned long long)h->ncomm), inject,
+                                 i + 1 < T_steps ? p.ring : nullptr, p.seq_theta, (long long)(i + 1)});
+            ++h->comm_submitted[sp];
+        }
+        h->comm_cv.notify_all();
+    }
+    int rc = rovmpc_comm_join(h, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(final_state_kernel, dim3(1), dim3(64), 0, s, d_state, d_exo, (const double *)d_results, (long long)T_steps, (int)R, 1);
+    HIPCHK(h, hipGetLastError());
+    return ROVMPC_OK;
+}
+
 extern "C" int rovmpc_closed_loop_pipelined_device(rovmpc_handle *h, const double *d_exo, int64_t T, double *d_state,
                                                    const void *d_pools, int32_t n_pools, int32_t feedback, double *d_results,
                                                    void *stream) {
@@ -2266,6 +2348,14 @@ extern "C" int rovmpc_closed_loop_device(rovmpc_handle *h, const double *d_exo, 
             if (rc) return rc;
         }
         return ROVMPC_OK;
+    }
+    // model feedback over the sharded step: the GPU-side hand-off (closed_loop_sharded_handoff_t) unless the model runs on the
+    // interpreter (no step kernel) or ROVMPC_CL_JOIN asks for the join-based form below
+    if (feedback && T > 1 && !getenv("ROVMPC_CL_JOIN") &&
+        (h->model_kind == MODEL_BUILTIN || (h->model_kind == MODEL_JIT && h->jit_fn_step))) {
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        return h->cfg.dtype == ROVMPC_F64 ? closed_loop_sharded_handoff_t<double>(h, d_exo, T, d_state, d_pools, n_pools, k_offset, d_results, s)
+                                          : closed_loop_sharded_handoff_t<float>(h, d_exo, T, d_state, d_pools, n_pools, k_offset, d_results, s);
     }
     for (int64_t i = 0; i < T; ++i) {
         const double *prev = (feedback && i > 0) ? d_results + (size_t)(i - 1) * R : nullptr;
