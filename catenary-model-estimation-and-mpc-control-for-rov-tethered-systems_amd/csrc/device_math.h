@@ -55,7 +55,7 @@ RV_DEV TrigK trig_constants(bool pin) {
 }
 
 RV_DEV void fast_sincos_k(double x, const TrigK &K, double *s, double *c) {
-    if (!(::fabs(x) < 67108864.0)) { const double2 r = slow_sincos_f64(x); *s = r.x; *c = r.y; return; }
+    const bool big = !(::fabs(x) < 67108864.0);
     const double k = ::rint(x * K.inv_pio2);
     double r = ::fma(-k, K.pio2_hi, x);
     r = ::fma(-k, K.pio2_lo, r);
@@ -68,8 +68,12 @@ RV_DEV void fast_sincos_k(double x, const TrigK &K, double *s, double *c) {
     const int q = (int)k;
     const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
     // signs: bit 1 of q (sine), bit 1 of q + 1 (cosine) into the sign bit
-    *s = __hiloint2double(__double2hiint(ss) ^ (int)(((unsigned)q & 2u) << 30), __double2loint(ss));
-    *c = __hiloint2double(__double2hiint(cc) ^ (int)(((unsigned)(q + 1) & 2u) << 30), __double2loint(cc));
+    double rs = __hiloint2double(__double2hiint(ss) ^ (int)(((unsigned)q & 2u) << 30), __double2loint(ss));
+    double rc = __hiloint2double(__double2hiint(cc) ^ (int)(((unsigned)(q + 1) & 2u) << 30), __double2loint(cc));
+    // large arguments (and NaN): the library's reduction, behind ONE wave-uniform branch -- a per-lane branch costs two
+    // exec-mask round trips on every call, taken or not
+    if (__builtin_amdgcn_ballot_w64(big) != 0) { const double2 r = slow_sincos_f64(x); if (big) { rs = r.x; rc = r.y; } }
+    *s = rs; *c = rc;
 }
 RV_DEV void fast_sincos_f64(double x, double *s, double *c) { fast_sincos_k(x, trig_constants(false), s, c); }
 
@@ -91,7 +95,7 @@ RV_DEV SinK sin_constants(bool pin) {
 constexpr double TRIG_FAST_LIMIT = 67108864.0;     // |x| below this: two-term Cody-Waite reduction is exact enough
 template <bool CHECKED = true>
 RV_DEV double fast_sin_k(double x, const SinK &K) {
-    if (CHECKED && !(::fabs(x) < TRIG_FAST_LIMIT)) return slow_sincos_f64(x).x;
+    const bool big = CHECKED && !(::fabs(x) < TRIG_FAST_LIMIT);
     const double k = ::rint(x * K.inv_pi);
     double r = ::fma(-k, K.pi_hi, x);
     r = ::fma(-k, K.pi_lo, r);
@@ -101,7 +105,9 @@ RV_DEV double fast_sin_k(double x, const SinK &K) {
     for (int i = 6; i >= 0; --i) p = ::fma(p, z, K.c[i]);
     const double v = ::fma(r * z, p, r);
     // sign (-1)^k: bit 0 of k into the sign bit (three instructions; the select form takes five)
-    return __hiloint2double(__double2hiint(v) ^ (int)((unsigned)(int)k << 31), __double2loint(v));
+    double res = __hiloint2double(__double2hiint(v) ^ (int)((unsigned)(int)k << 31), __double2loint(v));
+    if (CHECKED && __builtin_amdgcn_ballot_w64(big) != 0) { const double sl = slow_sincos_f64(x).x; if (big) res = sl; }
+    return res;
 }
 // fp32 (BASELINE config 3).  The device library's sinf / sincosf inline a Payne-Hanek reduction beside every call and
 // evaluate both polynomials for either result: ~40 instructions and six mask operations on the hot path, twice the fp64
@@ -114,7 +120,7 @@ __device__ __attribute__((noinline)) float slow_sinf_f32(float x) { return ::sin
 __device__ __attribute__((noinline)) float2 slow_sincos_f32(float x) { float s, c; ::sincosf(x, &s, &c); return make_float2(s, c); }
 template <bool CHECKED = true>
 RV_DEV float fast_sinf_k(float x) {
-    if (CHECKED && !(::fabsf(x) < TRIGF_FAST_LIMIT)) return slow_sinf_f32(x);
+    const bool big = CHECKED && !(::fabsf(x) < TRIGF_FAST_LIMIT);
     const float k = ::rintf(x * 0.318309886f);
     float r = ::fmaf(-k, 3.14159274f, x);
     r = ::fmaf(-k, -8.74227766e-8f, r);
@@ -123,10 +129,12 @@ RV_DEV float fast_sinf_k(float x) {
     p = ::fmaf(z, p, 0.008333237f);
     p = ::fmaf(z, p, -0.16666666f);
     const float v = ::fmaf(r * z, p, r);
-    return ((int)k & 1) ? -v : v;
+    float res = ((int)k & 1) ? -v : v;
+    if (CHECKED && __builtin_amdgcn_ballot_w64(big) != 0) { const float sl = slow_sinf_f32(x); if (big) res = sl; }
+    return res;
 }
 RV_DEV void fast_sincosf_k(float x, float *s, float *c) {
-    if (!(::fabsf(x) < TRIGF_FAST_LIMIT)) { const float2 r = slow_sincos_f32(x); *s = r.x; *c = r.y; return; }
+    const bool big = !(::fabsf(x) < TRIGF_FAST_LIMIT);
     const float k = ::rintf(x * 0.636619772f);
     float r = ::fmaf(-k, 1.57079637f, x);
     r = ::fmaf(-k, -4.37113883e-8f, r);
@@ -140,8 +148,9 @@ RV_DEV void fast_sincosf_k(float x, float *s, float *c) {
     const float cr = ::fmaf(z * z, pc, ::fmaf(z, -0.5f, 1.0f));
     const int q = (int)k;
     const float ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
-    *s = (q & 2) ? -ss : ss;
-    *c = ((q + 1) & 2) ? -cc : cc;
+    float rs = (q & 2) ? -ss : ss, rc = ((q + 1) & 2) ? -cc : cc;
+    if (__builtin_amdgcn_ballot_w64(big) != 0) { const float2 r = slow_sincos_f32(x); if (big) { rs = r.x; rc = r.y; } }
+    *s = rs; *c = rc;
 }
 
 // Trig context: fp64 carries the pinned constants, fp32 the kernels above (constants are 32-bit literals).

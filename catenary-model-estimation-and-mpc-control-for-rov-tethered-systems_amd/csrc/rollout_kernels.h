@@ -1501,20 +1501,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T xa[NEXO], xb[NEXO];
 #pragma unroll
             for (int sl = 0; sl < NEXO; ++sl) { xa[sl] = xb[sl] = T(0); if (in_lds(sl)) xa[sl] = RV_PX(sl, 0, c); }
-            // velocity-dependent slots of one node from (v, a, unit vector): simply.py:29-31, scaled
+            // velocity-dependent slots of one node from (v, a, unit vector): simply.py:29-31, scaled.  The scaling pairs of the
+            // slots in use sit in registers: read in the step they are an LDS round trip on the chain, every step (the
+            // progress word's store keeps the compiler from hoisting them)
+            T vmean[9], vinv[9];
+#pragma unroll
+            for (int sl = 3; sl < 9; ++sl) { vmean[sl] = vinv[sl] = T(0); if (uses(sl)) { vmean[sl] = sMean[sl]; vinv[sl] = sInv[sl]; } }
+            const T apmean = uses(13) ? sMean[apslot] : T(0), apinv = uses(13) ? sInv[apslot] : T(0);
+            const T g2m12 = gen2 ? sMean[12] : T(0), g2i12 = gen2 ? sInv[12] : T(0), g2m13 = gen2 ? sMean[13] : T(0), g2i13 = gen2 ? sInv[13] : T(0);
             auto vel_slots = [&](T *x, T vx, T vy, T vz, T ax, T ay, T az, T ux, T uy, T uz) {
                 if (uses(13)) {
                     const T nv = m_sqrtq(vx * vx + vy * vy + vz * vz) + T(1e-8);
                     T ap = (vx * ux + vy * uy + vz * uz) * fast_rcp(nv);      // nv >= 1e-8 (or NaN / inf, which stay that)
                     if (!gen2) ap = m_clip(ap, T(-1), T(1));
-                    x[13] = (ap - sMean[apslot]) * sInv[apslot];
+                    x[13] = (ap - apmean) * apinv;
                 }
-                if (uses(3)) x[3] = (vx - sMean[3]) * sInv[3];
-                if (uses(4)) x[4] = (vy - sMean[4]) * sInv[4];
-                if (uses(5)) x[5] = (vz - sMean[5]) * sInv[5];
-                if (uses(6)) x[6] = (ax - sMean[6]) * sInv[6];
-                if (uses(7)) x[7] = (ay - sMean[7]) * sInv[7];
-                if (uses(8)) x[8] = (az - sMean[8]) * sInv[8];
+                if (uses(3)) x[3] = (vx - vmean[3]) * vinv[3];
+                if (uses(4)) x[4] = (vy - vmean[4]) * vinv[4];
+                if (uses(5)) x[5] = (vz - vmean[5]) * vinv[5];
+                if (uses(6)) x[6] = (ax - vmean[6]) * vinv[6];
+                if (uses(7)) x[7] = (ay - vmean[7]) * vinv[7];
+                if (uses(8)) x[8] = (az - vmean[8]) * vinv[8];
             };
             T Vx = V0x, Vy = V0y, Vz = V0z;
             if (compose_rows)
@@ -1615,7 +1622,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T *g = cfrac2 == 0 ? gsa : (cfrac2 == 2 ? gsb : gsm);
                     if (gen2) {
                         // simulate_rk4_theta_gamma.py:40: [.., unit_rel, theta, gamma, cos(theta), sin(gamma), angle_proj]
-                        x[12] = (yth - sMean[12]) * sInv[12]; x[13] = (yga - sMean[13]) * sInv[13];
+                        x[12] = (yth - g2m12) * g2i12; x[13] = (yga - g2m13) * g2i13;
                         T s_t = st, c_t = ct, s_g = sg, c_g = cg;        // first stage: the node state itself
                         if (cfrac2 != 0) sincos_near2(yth, th, st, ct, s_t, c_t, yga, ga, sg, cg, s_g, c_g);
                         x[14] = (c_t - m14) * i14; x[15] = (s_g - m15) * i15;
