@@ -1491,8 +1491,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             RV_PL(sY, 0, 0, c) = th; RV_PL(sY, 1, 0, c) = ga;
             const T m14 = sMean[14], i14 = sInv[14], m15 = sMean[15], i15 = sInv[15];
             const T m16 = sMean[16], i16 = sInv[16], m17 = sMean[17], i17 = sInv[17];
-            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
-            const bool euler = a.integrator == ROVMPC_EULER;
+            const bool hold_rt = a.prev_mode == ROVMPC_PREV_HOLD;
+            const bool euler_rt = a.integrator == ROVMPC_EULER;
             const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * hstep, h6 = hstep / T(6);
             const bool gen2 = fmap == ROVMPC_FEATURES_GEN2;
             const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & VELMASK) != 0;
@@ -1587,9 +1587,11 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             exo_subs(xa, xb, 0, ea);
             // ROVMPC_JIT_TS: the end row's slope of a step is the next step's start slope when the delay slots are interpolated
             // (HOLD keeps the previous node's value through the step: its end row is not the next start row) and RK4 evaluates it
-            const bool carry_ok = ROVMPC_JIT_TS && !hold && !euler;
             T kA_carry = T(0);
-            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
+            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext, auto FAST) {
+                // FAST: the common mode (RK4, interpolated delay slots) with its flags as literals
+                const bool euler = FAST.value ? false : euler_rt, hold = FAST.value ? false : hold_rt;
+                const bool carry_ok = ROVMPC_JIT_TS && !hold && !euler;
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
@@ -1715,9 +1717,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 // progress word for the early phase-4b batch (one wave's DS operations complete in order)
                 if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
-            int n = 0;
-            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB); one_step(n + 1, xb, xa, eb, ea, opB, opA); }
-            if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB);
+            auto run = [&](auto FAST) {
+                int n = 0;
+                for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB, FAST); one_step(n + 1, xb, xa, eb, ea, opB, opA, FAST); }
+                if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB, FAST);
+            };
+            if (!euler_rt && !hold_rt) run(BoolC<true>{}); else run(BoolC<false>{});
         };
         // second-order generation, same scheme: every exogenous slot of features_dd hangs on the velocity, so under
         // VT_COMPOSE no row goes through LDS at all
