@@ -408,12 +408,16 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
 #ifdef ROVMPC_STAMPS
 #define RV_STAMP(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
 #define RV_STAMP_W(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)   // lane 0 of the calling wave
+// slot i <- SIMD of every wave of the workgroup: nibble w = 8 | SIMD_ID of wave w (HW_ID bits 5:4)
+#define RV_STAMP_SIMD(i) do { if ((threadIdx.x & 63) == 0 && a.stamps) atomicOr(&a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)], \
+    (unsigned long long)(8u | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3u)) << (4 * (threadIdx.x >> 6))); } while (0)
 // slot i <- HW_ID (hwreg 4: wave, simd, pipe, cu, sh, se) | XCC_ID (hwreg 20) << 32: which CU ran the workgroup
 #define RV_STAMP_HW(i) do { if (threadIdx.x == 0 && a.stamps) a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = \
     (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } while (0)
 #else
 #define RV_STAMP(i) do { } while (0)
 #define RV_STAMP_HW(i) do { } while (0)
+#define RV_STAMP_SIMD(i) do { } while (0)
 #define RV_STAMP_W(i) do { } while (0)
 #endif
 
@@ -744,6 +748,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
 
     RV_STAMP(1);
     RV_STAMP_HW(2);
+    RV_STAMP_SIMD(11);
     // ---- phase 2: exogenous feature rows of every node ------------------------------------
     // V_n (feature-frame velocity at node n) when it does not depend on (theta, gamma)
     auto vel = [&](int c, int node, T &vx, T &vy, T &vz) {
@@ -1738,17 +1743,22 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             const int nsteps = (a.debug & 1) ? 0 : N;
             T y0 = th0, y1 = ga0, y2 = thm0, y3 = gam0;
             RV_PL(sY, 0, 0, c) = y0; RV_PL(sY, 1, 0, c) = y1;
-            const bool euler = a.integrator == ROVMPC_EULER;
+            const bool euler_rt = a.integrator == ROVMPC_EULER;
             const T hstep = kk.h, inv_hstep = kk.inv_h, hh = T(0.5) * kk.h, h6 = kk.h / T(6);
             const bool compose_rows = VT == ROVMPC_VT_COMPOSE && (used & 0x3ffu) != 0;
             auto in_lds = [&](int p) { return uses(p) && VT != ROVMPC_VT_COMPOSE; };
             T xa[10], xb[10];
 #pragma unroll
             for (int p = 0; p < 10; ++p) { xa[p] = xb[p] = T(0); if (in_lds(p)) xa[p] = RV_PX(p, 0, c); }
+            // the scaling pairs of the state slots and of the exogenous slots in use, in registers (read in the step they are an
+            // LDS round trip on the chain: the progress word's store keeps the compiler from hoisting them)
+            T dmean[14], dinv[14];
+#pragma unroll
+            for (int p = 0; p < 14; ++p) { dmean[p] = dinv[p] = T(0); if (p < 4 || uses(p - 4)) { dmean[p] = sMean[p]; dinv[p] = sInv[p]; } }
             auto row = [&](T *x, T sway, T surge, T a_sway, T a_surge, T vx, T vy, T vz, T ax, T ay, T az) {
                 const T r[10] = {sway, surge, a_sway, a_surge, vs_reg * vx, vs_reg * vy, vs_reg * vz, vs_reg * ax, vs_reg * ay, vs_reg * az};
 #pragma unroll
-                for (int p = 0; p < 10; ++p) if (uses(p)) x[p] = (r[p] - sMean[4 + p]) * sInv[4 + p];
+                for (int p = 0; p < 10; ++p) if (uses(p)) x[p] = (r[p] - dmean[4 + p]) * dinv[4 + p];
             };
             T Vx = V0x, Vy = V0y, Vz = V0z, sway_p = T(0), surge_p = T(0);
             if (compose_rows)
@@ -1786,7 +1796,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 jit_exo<T>(x, e, trigj);
             };
             bool ea_ready = false;
-            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext) {
+            auto one_step = [&](int n, T *A, T *B, T *eA, T *eB, const Ops &o, Ops &onext, auto FAST) {
+                const bool euler = FAST.value ? false : euler_rt;          // FAST: RK4 with the flag as a literal
                 if (n + 1 < nsteps) fetch_ops(n + 1, onext);
                 if (compose_rows) {
                     const V3<T> kt = {o.ktx, o.kty, T(0)}, kg = {o.kgx, o.kgy, o.kgz};
@@ -1808,8 +1819,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     T x[18];
                     fill_exo(x, A, B, cfrac2);
                     const T *e = cfrac2 == 0 ? eA : (cfrac2 == 2 ? eB : em);
-                    x[0] = (s0 - sMean[0]) * sInv[0]; x[1] = (s1 - sMean[1]) * sInv[1];
-                    x[2] = (s2 - sMean[2]) * sInv[2]; x[3] = (s3 - sMean[3]) * sInv[3];
+                    x[0] = (s0 - dmean[0]) * dinv[0]; x[1] = (s1 - dmean[1]) * dinv[1];
+                    x[2] = (s2 - dmean[2]) * dinv[2]; x[3] = (s3 - dmean[3]) * dinv[3];
                     ddth = jit_f_theta<T>(x, e, (const T *)nullptr, trigj);
                     ddga = jit_f_gamma<T>(x, e, trigj);
                 };
@@ -1843,9 +1854,12 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 RV_PL(sY, 0, n + 1, c) = y0; RV_PL(sY, 1, n + 1, c) = y1;
                 if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
-            int n = 0;
-            for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB); one_step(n + 1, xb, xa, eb, ea, opB, opA); }
-            if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB);
+            auto run = [&](auto FAST) {
+                int n = 0;
+                for (; n + 1 < nsteps; n += 2) { one_step(n, xa, xb, ea, eb, opA, opB, FAST); one_step(n + 1, xb, xa, eb, ea, opB, opA, FAST); }
+                if (n < nsteps) one_step(n, xa, xb, ea, eb, opA, opB, FAST);
+            };
+            if (!euler_rt) run(BoolC<true>{}); else run(BoolC<false>{});
         };
         const bool wide = NT > nint;
         if (tid < nint) {

@@ -1528,6 +1528,7 @@ extern "C" int rovmpc_diag_read_stamps(rovmpc_handle *h, unsigned long long *out
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->d_stamps, (size_t)h->nblocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->d_stamps, 0, (size_t)h->nblocks * 16 * sizeof(unsigned long long)));   // (slot 11 is OR-ed into)
     if (nblocks) *nblocks = h->nblocks;
     return ROVMPC_OK;
 }

@@ -44,11 +44,14 @@ lib = eng.lib
 lib.rovmpc_diag_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
 buf = np.zeros((K, 16), dtype=np.uint64)
 nb = C.c_int32()
+if not os.environ.get("STAMPS_BACK_TO_BACK"):     # clear what the warm-up launches left, then one launch to read
+    lib.rovmpc_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), C.byref(nb))
+    eng.step(state, U)
 assert lib.rovmpc_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
 st = buf[:nb.value].astype(np.int64)
 t0 = st[:, 0].min()
 names = ["start", "U in LDS", None, "features done", "integration done", "geometry done", "outputs stored", "ticket drawn",
-         "gamma wave: chain starts", "gamma wave: chain done", "gamma wave: sines done", "gamma wave: positions done", "phase 2a done (wave 0)", "phase 2a barrier passed", "phase 5: block arg-min done", "phase 5: barrier passed"]
+         "gamma wave: chain starts", "gamma wave: chain done", "gamma wave: sines done", None, "phase 2a done (wave 0)", "phase 2a barrier passed", "phase 5: block arg-min done", "phase 5: barrier passed"]
 print(f"{nb.value} workgroups; times in us from the first workgroup's start (100 MHz clock)")
 for i, n in enumerate(names):
     if n is None:
@@ -59,6 +62,13 @@ for i, n in enumerate(names):
         continue
     print(f"  {n:18s} median {np.median(col - t0) / 100:7.2f}   min {(col.min() - t0) / 100:7.2f}   max {(col.max() - t0) / 100:7.2f}")
 
+# slot 11: nibble w = 8 | SIMD of wave w
+import collections
+pat = collections.Counter()
+for v in buf[:nb.value, 11]:
+    v = int(v)
+    pat["".join(str((v >> (4 * w)) & 3) if (v >> (4 * w)) & 8 else "-" for w in range(8))] += 1
+print("SIMD of waves 0..7 (pattern: workgroups):", dict(pat.most_common(8)))
 print("per workgroup, us after ITS OWN start (median / p10 / p90):")
 for i, n in enumerate(names):
     if n is None or i == 0:
