@@ -1105,6 +1105,17 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T X3[2], SX[2];
             X3[0] = (V0x - m3) * i3; X3[1] = T(0);
             SX[0] = trig.sin(X3[0]); SX[1] = T(0);
+            // RK4 with the interpolated delay slot, arranged for the chain's DEPTH (one wave issues a dependent instruction
+            // every ~9.5 cycles, an independent one every ~5: tools/micro/fma_latency.hip):
+            //  * the lane's sine argument -- x3b on the end lane, (x3a + x3b) / 2 on the midpoint lane -- is ONE FMA,
+            //    hf * x3b + HA with hf = 1 | 1/2 and HA = 0 | x3a / 2 (the same value as the sum halved: halving is exact);
+            //  * every node's share of the sum, w = -sin x3 - 3 x3 - K16b / 2, is formed once and carried to the next step;
+            //    what waits for the step's sines is  S = (base - 4 sin x3m) + w_end  with base = G_n + w_start - K16a (theta_{n-1}
+            //    + theta_n) ready long before them.
+            const T hf = (role & 1) ? T(0.5) : T(1), hq = (role & 1) ? T(0.5) : T(0);
+            const T mK16bh = T(-0.5) * K16b;
+            T HA[2] = {hq * X3[0], T(0)};
+            T W[2] = {m_fma(T(-3), X3[0], mK16bh) - SX[0], T(0)};
             // operands of step n, fetched one step ahead (nothing in the loop waits on another wave)
             T OA[2] = {T(0), T(0)}, OB[2] = {T(0), T(0)}, OC[2] = {T(0), T(0)}, GG[2] = {T(0), T(0)};
             auto fetch = [&](int n, int q) {
@@ -1131,23 +1142,25 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                 // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
                 // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
                 if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
-                const T x3s = x3a + x3b;
-                const T x3m = x3s / T(2);                                  // :62 feature midpoint
-                const T sarg = (role & 1) ? x3m : x3b;
+                const T sarg = m_fma(hf, x3b, HA[p]);                      // x3b | the feature midpoint (x3a + x3b) / 2 (:62)
                 const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
                 T s2r[4];
                 quad4(s2, s2r);
                 const T sinXb = s2r[0], sinXm = s2r[1];
-                // delay slot x16 at the two ends of the step (np.roll semantics, simply.py:35-38)
-                const T s16a = (thm - m16) * i16;
                 T S;
-                if (eul) {
-                    S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
+                if (eul || hld) {
+                    // delay slot x16 at the start of the step (np.roll semantics, simply.py:35-38)
+                    const T s16a = (thm - m16) * i16;
+                    if (eul) S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
+                    else S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - T(6) * s16a) - T(3) * (x3a + x3b);   // :66, delay slot held
                 } else {
-                    // 3 (s16a + s16b) = 3 ((thm + th) - 2 m16) / scale16, as one FMA on the chain (constants hoisted: K16a, K16b)
-                    const T s16 = hld ? T(6) * s16a : (thm + th) * K16a + K16b;
-                    S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - s16) - T(3) * x3s;   // :66
+                    // :66 -- 3 (s16a + s16b) = K16a (theta_{n-1} + theta_n) + K16b
+                    const T base = m_fma(-K16a, thm + th, Gn + W[p]);
+                    const T wb = m_fma(T(-3), x3b, mK16bh) - sinXb;
+                    S = m_fma(T(-4), sinXm, base) + wb;
+                    W[q] = wb;
                 }
+                HA[q] = hq * x3b;
                 const T thn = th + hKT * S;
                 if (VT == ROVMPC_VT_COMPOSE) {
                     // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
