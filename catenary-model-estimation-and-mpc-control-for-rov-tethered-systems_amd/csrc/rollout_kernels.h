@@ -403,6 +403,13 @@ RV_DEV void argmin_epilogue(const RolloutArgs<T> &a, const unsigned long long *g
 
 // ---- the kernel ---------------------------------------------------------------------------
 
+// A theta slot somebody waits for holds this marker (a NaN payload no computation produces) until the integrating wave
+// stores the node: relaxed 32/64-bit LDS accesses, single-copy atomic.
+RV_DEV void theta_slot_mark(double *p) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), 0x7ff85ea71e5007e7ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RV_DEV void theta_slot_mark(float *p) { __hip_atomic_store(reinterpret_cast<unsigned int *>(p), 0x7fc5ea71u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RV_DEV bool theta_slot_marked(double *p) { return __hip_atomic_load(reinterpret_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0x7ff85ea71e5007e7ull; }
+RV_DEV bool theta_slot_marked(float *p) { return __hip_atomic_load(reinterpret_cast<unsigned int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0x7fc5ea71u; }
+
 // In-kernel phase stamps exist only in the diagnostic library (make diag, -DROVMPC_STAMPS); the
 // product library contains none of this code.
 #ifdef ROVMPC_STAMPS
@@ -922,6 +929,27 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             node_item(n, c, Px, Py, Pz);
         }
     }
+    // items taken through phase 4b early (compiled-in model, one theta wave, at least one pure geometry wave)
+    int early = 0;
+    if (MODEL == MODEL_BUILTIN && CK <= 16 && NT >= 64 + 64 + 64 && N * CK > 256) {
+        const int r = (N * CK) % 256;
+        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
+    }
+    // (hiprtc-specialised models: one integrating wave, the others on the geometry; same early batch, taken by the first
+    // geometry wave while the integration runs)
+    if (MODEL == MODEL_JIT && CK <= 64 && NT >= 64 + 64 && N * CK > 256) {
+        const int r = (N * CK) % 256;
+        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
+    }
+    // Long horizons (compiled-in model, one theta wave): when the join would leave MORE than one round of phase 4b, the
+    // geometry waves chase the theta wave instead -- every pool thread owns the items tid, tid + pool, ..., takes them through
+    // 4a at once and through 4b as soon as the theta wave has passed their node, so that after the last integration step only
+    // the last nodes' batch is left (C3, N = 50: two rounds = 3.7 us after the join -> one batch).  With a single round left
+    // (C2, the throughput geometries) the chase gains nothing -- that round runs on every SIMD after the join, a chased batch
+    // on one -- and the extra waves slow the integrating one (measured in round 1): those keep the early batch only.
+    const bool chase = LONGH && MODEL == MODEL_BUILTIN && CK <= 16 && wideB && N * CK - early > NT;
+    // the integrating wave reports its progress only as far as somebody waits for it (the nodes of the early batch)
+    const int prog_until = chase ? N : (early > 0 ? (early + CK - 1) / CK : 0);
     RV_STAMP(12);
     if (MODEL == MODEL_BUILTIN && share_sines) {
         while (__hip_atomic_load(s_chain_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(4);
@@ -931,6 +959,9 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     RV_STAMP(13);
     const bool gtab_loaded = MODEL == MODEL_BUILTIN && share_sines && *s_chain_done == 2;
     if (MODEL == MODEL_BUILTIN) {
+        // the theta nodes somebody will wait for (early batch / chase) start as a marker: the waiting lane polls its own
+        // node's slot -- the integrating wave publishes no progress word (eight instructions of its every step)
+        for (int i = tid; i < prog_until * CK; i += NT) theta_slot_mark(&RV_PL(sY, 0, 1 + (i >> cks), i & ckm));
         if (share_sines && !gtab_loaded) gamma_G(tid, NT);           // (its reads are the shared sines; the theta chain reads it behind the next barrier)
         // ---- phase 2b: what hangs on gamma_n alone, for every (node, candidate): the gamma plane and the
         // first half of the velocity transform ------------------------------------------------------------
@@ -1038,27 +1069,6 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         const T flo = m_max(T(0), kk.up * (kk.z_floor - zl));
         sC[n * CK + c] = kk.w_theta * (eth * eth) + kk.w_gamma * (ega * ega) + sC[n * CK + c] + kk.w_floor * (flo * flo);
     };
-    // items taken through phase 4b early (compiled-in model, one theta wave, at least one pure geometry wave)
-    int early = 0;
-    if (MODEL == MODEL_BUILTIN && CK <= 16 && NT >= 64 + 64 + 64 && N * CK > 256) {
-        const int r = (N * CK) % 256;
-        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
-    }
-    // (hiprtc-specialised models: one integrating wave, the others on the geometry; same early batch, taken by the first
-    // geometry wave while the integration runs)
-    if (MODEL == MODEL_JIT && CK <= 64 && NT >= 64 + 64 && N * CK > 256) {
-        const int r = (N * CK) % 256;
-        if (r > 0 && r <= 64 && (r + CK - 1) / CK <= N / 2) early = r;
-    }
-    // Long horizons (compiled-in model, one theta wave): when the join would leave MORE than one round of phase 4b, the
-    // geometry waves chase the theta wave instead -- every pool thread owns the items tid, tid + pool, ..., takes them through
-    // 4a at once and through 4b as soon as the theta wave has passed their node, so that after the last integration step only
-    // the last nodes' batch is left (C3, N = 50: two rounds = 3.7 us after the join -> one batch).  With a single round left
-    // (C2, the throughput geometries) the chase gains nothing -- that round runs on every SIMD after the join, a chased batch
-    // on one -- and the extra waves slow the integrating one (measured in round 1): those keep the early batch only.
-    const bool chase = LONGH && MODEL == MODEL_BUILTIN && CK <= 16 && wideB && N * CK - early > NT;
-    // the integrating wave reports its progress only as far as somebody waits for it (the nodes of the early batch)
-    const int prog_until = chase ? N : (early > 0 ? (early + CK - 1) / CK : 0);
     if (MODEL == MODEL_BUILTIN) {
         // saved_models/equations_dtheta_dt.csv complexity 13:
         //   ((((sin(x17) - sin(x3)) - x16) - x3) * 0.048152514)      -- no dependence on the stage state
@@ -1133,67 +1143,85 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th0, &st, &ct);
             // One loop for the common mode (RK4, interpolated delay slot, bounded sine arguments) with its flags
             // as literals, one for everything else with run-time flags.
+            // Angle addition holds for |d| < 2^-7.  A lane whose step is larger needs the full evaluation -- but a vote and a branch
+            // right behind the compare stall the chain in every step.  The common mode therefore only NOTES the large lanes
+            // (late) and tests the note one step later, when the compare has long retired: if it was set, sincos(theta_n) of
+            // those lanes is evaluated in full and the step, already run through with the poor pair, is run again before anything
+            // of it is published.  Same values as deciding at once (what the run-time-flag loop does).
+            bool late = false;
             auto one_step = [&](auto FAST, auto PAR, int n) {
                 constexpr int p = PAR.value ? 1 : 0, q = p ^ 1;
+                constexpr bool DEFER = FAST.value && VT == ROVMPC_VT_COMPOSE;
                 const bool eul = FAST.value ? false : euler, hld = FAST.value ? false : hold, bnd = FAST.value ? true : bounded;
                 const T thm = TH[p], th = TH[q], x3a = X3[p], sinXa = SX[p];
-                const T x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
                 const T Gn = GG[p];
-                // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
-                // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
-                if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
-                const T sarg = m_fma(hf, x3b, HA[p]);                      // x3b | the feature midpoint (x3a + x3b) / 2 (:62)
-                const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
-                T s2r[4];
-                quad4(s2, s2r);
-                const T sinXb = s2r[0], sinXm = s2r[1];
-                T S;
-                if (eul || hld) {
-                    // delay slot x16 at the start of the step (np.roll semantics, simply.py:35-38)
-                    const T s16a = (thm - m16) * i16;
-                    if (eul) S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
-                    else S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - T(6) * s16a) - T(3) * (x3a + x3b);   // :66, delay slot held
-                } else {
-                    // :66 -- 3 (s16a + s16b) = K16a (theta_{n-1} + theta_n) + K16b
-                    const T base = m_fma(-K16a, thm + th, Gn + W[p]);
-                    const T wb = m_fma(T(-3), x3b, mK16bh) - sinXb;
-                    S = m_fma(T(-4), sinXm, base) + wb;
-                    W[q] = wb;
-                }
-                HA[q] = hq * x3b;
-                const T thn = th + hKT * S;
-                if (VT == ROVMPC_VT_COMPOSE) {
-                    // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
-                    // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
-                    const T dlt = thn - th;
-                    const bool big = !(m_abs(dlt) < T(0.0078125));
-                    auto advance = [&]() {
-                        // |d| < 2^-7: the first neglected terms, d^7 / 5040 and d^8 / 40320, are below 4e-19 (absolute, of
-                        // values of size one): sixteen steps between two anchors add up to less than 1e-17
-                        const T d2 = dlt * dlt;
-                        const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20)));
-                        const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30)));
-                        const T sn = st * cd + ct * sd;
-                        ct = ct * cd - st * sd;
-                        st = sn;
-                    };
-                    if (((n + 1) & 15) == 0) {
-                        trig.sincos(thn, &st, &ct);
-                    } else if (!__any(big)) {
-                        advance();
-                    } else {                                   // rare: some lane of the wave took a large step
-                        T fs, fc;
-                        trig.sincos(thn, &fs, &fc);
-                        advance();
-                        if (big) { st = fs; ct = fc; }
+                T thn, stn = st, ctn = ct, x3b, sinXb;
+                bool late_n = false;
+                for (;;) {
+                    x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
+                    // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
+                    // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
+                    if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
+                    const T sarg = m_fma(hf, x3b, HA[p]);                  // x3b | the feature midpoint (x3a + x3b) / 2 (:62)
+                    const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
+                    T s2r[4];
+                    quad4(s2, s2r);
+                    sinXb = s2r[0];
+                    const T sinXm = s2r[1];
+                    T S;
+                    if (eul || hld) {
+                        // delay slot x16 at the start of the step (np.roll semantics, simply.py:35-38)
+                        const T s16a = (thm - m16) * i16;
+                        if (eul) S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
+                        else S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - T(6) * s16a) - T(3) * (x3a + x3b);   // :66, delay slot held
+                    } else {
+                        // :66 -- 3 (s16a + s16b) = K16a (theta_{n-1} + theta_n) + K16b
+                        const T base = m_fma(-K16a, thm + th, Gn + W[p]);
+                        const T wb = m_fma(T(-3), x3b, mK16bh) - sinXb;
+                        S = m_fma(T(-4), sinXm, base) + wb;
+                        W[q] = wb;
                     }
+                    HA[q] = hq * x3b;
+                    thn = th + hKT * S;
+                    if (VT == ROVMPC_VT_COMPOSE) {
+                        // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
+                        // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
+                        const T dlt = thn - th;
+                        const bool big = !(m_abs(dlt) < T(0.015625));
+                        auto advance = [&]() {
+                            // |d| < 2^-6: the first neglected terms, d^9 / 362880 and d^8 / 40320, are below 1e-19 (absolute, of
+                            // values of size one): sixteen steps between two anchors add up to less than 2e-18.  (The bound was
+                            // 2^-7 with one term less: on the synthetic workload one wave-step in eight then held a lane beyond it.)
+                            const T d2 = dlt * dlt;
+                            const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+                            const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30)));
+                            stn = st * cd + ct * sd;
+                            ctn = ct * cd - st * sd;
+                        };
+                        if (PAR.value && ((n + 1) & 15) == 0) {        // (anchors fall on odd steps)
+                            trig.sincos(thn, &stn, &ctn);
+                        } else if (DEFER) {
+                            advance();
+                            late_n = big;
+                        } else if (!__any(big)) {
+                            advance();
+                        } else {                                   // rare: some lane of the wave took a large step
+                            T fs, fc;
+                            trig.sincos(thn, &fs, &fc);
+                            advance();
+                            if (big) { stn = fs; ctn = fc; }
+                        }
+                    }
+                    if (!DEFER || !__any(late)) break;
+                    T fs, fc;                                      // rare: the step before this one was large on some lane
+                    trig.sincos(th, &fs, &fc);
+                    if (late) { st = fs; ct = fc; }
+                    late = false;
                 }
+                st = stn; ct = ctn; late = late_n;
                 TH[p] = thn;                                   // over theta_{n-1}, dead from here
                 X3[q] = x3b; SX[q] = sinXb;
-                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;
-                // progress word for the early phase-4b batch: one wave's DS operations complete in order,
-                // so the relaxed store cannot pass the theta store above
-                if (n < prog_until && tid == 0) __hip_atomic_store(&s_prog[1], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;    // (whoever waits for this node polls the slot: theta_slot_wait)
             };
             auto run = [&](auto FAST) {
                 int n = 0;
@@ -1228,7 +1256,10 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         else if (own) { b0 = j; b1 = j + 1; }
         for (int i = b0; i < b1; i += bs) {
             const int n = i >> cks;
-            while (__hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n + 1) __builtin_amdgcn_s_sleep(8);
+            // until the node's theta is there -- or the chain is through (a theta that IS the marker's bit pattern, a NaN
+            // payload handed in with the inputs, is then simply read)
+            while (theta_slot_marked(&RV_PL(sY, 0, n + 1, i & ckm)) &&
+                   __hip_atomic_load(&s_prog[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < N) __builtin_amdgcn_s_sleep(4);
             geometry_b_item(n, i & ckm);
         }
         if (chase) early = N * CK;                    // nothing is left for the round after the join

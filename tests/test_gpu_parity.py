@@ -690,6 +690,30 @@ def test_a_candidate_does_not_depend_on_its_neighbours(rv):
         assert np.array_equal(traj[5], traj[k]) and np.array_equal(traj2[5], traj2[k]) and np.array_equal(traj[5], traj2[k])
 
 
+@pytest.mark.parametrize("scale,K", [(20.0, 64), (40.0, 40), (20.0, 4096)])
+def test_theta_steps_beyond_the_angle_addition_bound(rv, orc, scale, K):
+    """Steps with |theta_{n+1} - theta_n| beyond the bound of the angle addition (fast vehicles): the chain notes them and, one
+    step later, replaces the angle-addition sincos of those lanes by a full evaluation and runs the step again -- mixed with
+    small steps in the same waves (controls x 20) and in most steps (x 40).  dt = 1/60: the
+    reference's gamma equation amplifies rounding by 1e20 over twenty steps of 0.05 s, which would test nothing.
+    Against the oracle, and the records of equal candidates bit for bit."""
+    cfg = rv.MPCConfig(N=20, K=K, dt=1 / 60)
+    state, U = rv.synthetic_problem(cfg.K, cfg.N, seed=33)
+    U *= scale
+    U[K - 3] = U[1]
+    model = rv.default_model()
+    with rv.Engine(cfg, model) as e:
+        J, traj = e.rollout_costs(state, U, return_traj=True)
+        res = e.step(state, U)
+    Jo, trajo, _ = orc.rollout_vec(oracle_cfg(orc, cfg), oracle_model(orc, model), orc.MPCState.from_array(state), U)
+    d = np.abs(np.diff(trajo[:, :, 0], axis=1))
+    assert (d >= 2.0 ** -6).mean() > 0.1 and (d < 2.0 ** -6).mean() > 0.1
+    np.testing.assert_allclose(traj, trajo, rtol=RTOL, atol=1e-13)
+    np.testing.assert_allclose(J, Jo, rtol=RTOL)
+    assert res.index == int(np.argmin(Jo))
+    assert J[1] == J[K - 3] and np.array_equal(traj[1], traj[K - 3])
+
+
 @pytest.mark.parametrize("N,K,dt,vt", [(150, 40, 1 / 240, 1), (100, 33, 1 / 240, 0), (21, 1, 1 / 60, 1), (23, 4097, 1 / 60, 1)])
 def test_long_horizons_and_odd_sizes(rv, orc, N, K, dt, vt):
     """Horizons beyond one round of the table passes (3N + 2 > 64 items on the gamma wave), small workgroups forced
