@@ -1143,85 +1143,62 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             if (VT == ROVMPC_VT_COMPOSE) trig.sincos(th0, &st, &ct);
             // One loop for the common mode (RK4, interpolated delay slot, bounded sine arguments) with its flags
             // as literals, one for everything else with run-time flags.
-            // Angle addition holds for |d| < 2^-7.  A lane whose step is larger needs the full evaluation -- but a vote and a branch
-            // right behind the compare stall the chain in every step.  The common mode therefore only NOTES the large lanes
-            // (late) and tests the note one step later, when the compare has long retired: if it was set, sincos(theta_n) of
-            // those lanes is evaluated in full and the step, already run through with the poor pair, is run again before anything
-            // of it is published.  Same values as deciding at once (what the run-time-flag loop does).
-            bool late = false;
             auto one_step = [&](auto FAST, auto PAR, int n) {
                 constexpr int p = PAR.value ? 1 : 0, q = p ^ 1;
-                constexpr bool DEFER = FAST.value && VT == ROVMPC_VT_COMPOSE;
                 const bool eul = FAST.value ? false : euler, hld = FAST.value ? false : hold, bnd = FAST.value ? true : bounded;
                 const T thm = TH[p], th = TH[q], x3a = X3[p], sinXa = SX[p];
                 const T Gn = GG[p];
-                T thn, stn = st, ctn = ct, x3b, sinXb;
-                bool late_n = false;
-                for (;;) {
-                    x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
-                    // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
-                    // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
-                    if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
-                    const T sarg = m_fma(hf, x3b, HA[p]);                  // x3b | the feature midpoint (x3a + x3b) / 2 (:62)
-                    const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
-                    T s2r[4];
-                    quad4(s2, s2r);
-                    sinXb = s2r[0];
-                    const T sinXm = s2r[1];
-                    T S;
-                    if (eul || hld) {
-                        // delay slot x16 at the start of the step (np.roll semantics, simply.py:35-38)
-                        const T s16a = (thm - m16) * i16;
-                        if (eul) S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
-                        else S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - T(6) * s16a) - T(3) * (x3a + x3b);   // :66, delay slot held
-                    } else {
-                        // :66 -- 3 (s16a + s16b) = K16a (theta_{n-1} + theta_n) + K16b
-                        const T base = m_fma(-K16a, thm + th, Gn + W[p]);
-                        const T wb = m_fma(T(-3), x3b, mK16bh) - sinXb;
-                        S = m_fma(T(-4), sinXm, base) + wb;
-                        W[q] = wb;
-                    }
-                    HA[q] = hq * x3b;
-                    thn = th + hKT * S;
-                    if (VT == ROVMPC_VT_COMPOSE) {
-                        // per lane: full evaluation at the anchors and for a lane whose own step is large, angle
-                        // addition otherwise -- a candidate's arithmetic never depends on its neighbours in the wave
-                        const T dlt = thn - th;
-                        const bool big = !(m_abs(dlt) < T(0.015625));
-                        auto advance = [&]() {
-                            // |d| < 2^-6: the first neglected terms, d^9 / 362880 and d^8 / 40320, are below 1e-19 (absolute, of
-                            // values of size one): sixteen steps between two anchors add up to less than 2e-18.  (The bound was
-                            // 2^-7 with one term less: on the synthetic workload one wave-step in eight then held a lane beyond it.)
-                            const T d2 = dlt * dlt;
-                            const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
-                            const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30)));
-                            stn = st * cd + ct * sd;
-                            ctn = ct * cd - st * sd;
-                        };
-                        if (PAR.value && ((n + 1) & 15) == 0) {        // (anchors fall on odd steps)
-                            trig.sincos(thn, &stn, &ctn);
-                        } else if (DEFER) {
-                            advance();
-                            late_n = big;
-                        } else if (!__any(big)) {
-                            advance();
-                        } else {                                   // rare: some lane of the wave took a large step
-                            T fs, fc;
-                            trig.sincos(thn, &fs, &fc);
-                            advance();
-                            if (big) { stn = fs; ctn = fc; }
-                        }
-                    }
-                    if (!DEFER || !__any(late)) break;
-                    T fs, fc;                                      // rare: the step before this one was large on some lane
-                    trig.sincos(th, &fs, &fc);
-                    if (late) { st = fs; ct = fc; }
-                    late = false;
+                const T x3b = VT == ROVMPC_VT_COMPOSE ? (OB[p] + OC[p] * ct) + OA[p] * st : OB[p];
+                // (the operands of a step past the horizon are never used; with the composed transform their rows exist --
+                // the planes and the table have N + 1 of them -- so the last step fetches like the others, without a guard)
+                if (VT == ROVMPC_VT_COMPOSE || n + 1 < nsteps) fetch(n + 1, q);
+                const T sarg = m_fma(hf, x3b, HA[p]);                      // x3b | the feature midpoint (x3a + x3b) / 2 (:62)
+                const T s2 = bnd ? trig.sin_bounded(sarg) : trig.sin(sarg);
+                T s2r[4];
+                quad4(s2, s2r);
+                const T sinXb = s2r[0], sinXm = s2r[1];
+                T S;
+                if (eul || hld) {
+                    // delay slot x16 at the start of the step (np.roll semantics, simply.py:35-38)
+                    const T s16a = (thm - m16) * i16;
+                    if (eul) S = ((Gn - sinXa) - s16a) - x3a;                       // main_fun.py:761
+                    else S = ((Gn - ((sinXa + sinXb) + T(4) * sinXm)) - T(6) * s16a) - T(3) * (x3a + x3b);   // :66, delay slot held
+                } else {
+                    // :66 -- 3 (s16a + s16b) = K16a (theta_{n-1} + theta_n) + K16b
+                    const T base = m_fma(-K16a, thm + th, Gn + W[p]);
+                    const T wb = m_fma(T(-3), x3b, mK16bh) - sinXb;
+                    S = m_fma(T(-4), sinXm, base) + wb;
+                    W[q] = wb;
                 }
-                st = stn; ct = ctn; late = late_n;
+                HA[q] = hq * x3b;
+                const T thn = th + hKT * S;
+                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;    // (whoever waits for this node polls the slot: theta_slot_wait)
+                if (VT == ROVMPC_VT_COMPOSE) {
+                    // per lane: angle addition; the full evaluation at the anchors and for a lane whose own step is large -- a
+                    // candidate's arithmetic never depends on its neighbours in the wave.  The vote on the large lanes comes
+                    // AFTER the addition: behind the compare it would stall the chain in every step (a wave issues a dependent
+                    // instruction every ~9.5 cycles), and a branch in the middle of the step keeps the scheduler from filling
+                    // the sine's dependent chain with the step's independent work.
+                    const T dlt = thn - th;
+                    const bool big = !(m_abs(dlt) < T(0.015625));
+                    // |d| < 2^-6: the first neglected terms, d^9 / 362880 and d^8 / 40320, are below 1e-19 (absolute, of
+                    // values of size one): sixteen steps between two anchors add up to less than 2e-18.  (The bound was
+                    // 2^-7 with one term less: on the synthetic workload one wave-step in eight then held a lane beyond it.)
+                    const T d2 = dlt * dlt;
+                    const T sd = dlt * (T(1) - d2 * T(1.0 / 6) * (T(1) - d2 * T(1.0 / 20) * (T(1) - d2 * T(1.0 / 42))));
+                    const T cd = T(1) - d2 * T(0.5) * (T(1) - d2 * T(1.0 / 12) * (T(1) - d2 * T(1.0 / 30)));
+                    const T sn = st * cd + ct * sd;
+                    ct = ct * cd - st * sd;
+                    st = sn;
+                    const bool anchor = PAR.value && ((n + 1) & 15) == 0;        // (anchors fall on odd steps)
+                    if (anchor || __any(big)) {                                   // rare
+                        T fs, fc;
+                        trig.sincos(thn, &fs, &fc);
+                        if (anchor || big) { st = fs; ct = fc; }
+                    }
+                }
                 TH[p] = thn;                                   // over theta_{n-1}, dead from here
                 X3[q] = x3b; SX[q] = sinXb;
-                if (live && role == 0) RV_PL(sY, 0, n + 1, c) = thn;    // (whoever waits for this node polls the slot: theta_slot_wait)
             };
             auto run = [&](auto FAST) {
                 int n = 0;
