@@ -586,8 +586,14 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             }
             return s15 - p17;
         };
-        auto run = [&](auto HOLD, auto EULER) {
-            for (int n = 0; n < nsteps; ++n) {
+        // Horizons of up to 64 steps can keep the path in registers -- lane n holds gamma_{n+1} -- and store it once behind
+        // the loop: a masked store and its two jumps in every step of the chain cost more than three selects; with two steps
+        // per trip, the second on the first one's names, there is no copy of gamma_n on the chain either (C2: -0.4 us).  As
+        // a literal of the loop only: the plain short-horizon instance always (N <= 20 there), the hand-off and sampling
+        // instances through a second copy of the loop.  (Long-horizon instance: measured, +0.2 us at C3 -- as it was.)
+        T kept = T(0);
+        auto run = [&](auto HOLD, auto EULER, auto KEEP) {
+            auto one = [&](int n, const T gam, const T ga) -> T {
                 const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;      // np.roll delay slot, simply.py:35-38
                 const T p17m = HOLD.value ? s17a : (s17a + s17b) / T(2);
                 const T p17e = HOLD.value ? s17a : s17b;
@@ -604,14 +610,31 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                         sG[GROW * n + 2] = ga + hh * k1g; sG[GROW * n + 3] = ga + hh * k2g; sG[GROW * n + 4] = ga + hstep * k3g;
                     }
                 }
-                if (lane == 0) sG[GROW * n + 5] = gan;
-                gam = ga; ga = gan;
+                if (KEEP.value) { if (lane == n) kept = gan; }
+                else if (lane == 0) sG[GROW * n + 5] = gan;
+                return gan;
+            };
+            int n = 0;
+            if (KEEP.value) {
+                for (; n + 1 < nsteps; n += 2) {
+                    const T g1 = one(n, gam, ga);
+                    const T g2 = one(n + 1, ga, g1);
+                    gam = g1; ga = g2;
+                }
             }
+            for (; n < nsteps; ++n) { const T g1 = one(n, gam, ga); gam = ga; ga = g1; }
+            if (KEEP.value && lane < nsteps) sG[GROW * lane + 5] = kept;
         };
-        const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
-        if (a.integrator == ROVMPC_EULER) run(BoolC<false>{}, BoolC<true>{});
-        else if (hold) run(BoolC<true>{}, BoolC<false>{});
-        else run(BoolC<false>{}, BoolC<false>{});
+        auto run_mode = [&](auto KEEP) {
+            const bool hold = a.prev_mode == ROVMPC_PREV_HOLD;
+            if (a.integrator == ROVMPC_EULER) run(BoolC<false>{}, BoolC<true>{}, KEEP);
+            else if (hold) run(BoolC<true>{}, BoolC<false>{}, KEEP);
+            else run(BoolC<false>{}, BoolC<false>{}, KEEP);
+        };
+        constexpr bool CAN_KEEP = !JGI && MODEL == MODEL_BUILTIN && !LONGH;
+        if (CAN_KEEP && !HANDOFF && !SAMPLE) run_mode(BoolC<true>{});
+        else if (CAN_KEEP && N <= 64) run_mode(BoolC<true>{});
+        else run_mode(BoolC<false>{});
     };
     // G_n = sinA + 4 sinM + sinE (RK4; sinA for Euler), sinA_n = sin(x17 at t_n) = row n-1's [3]
     auto gamma_G = [&](int first, int stride) {
@@ -628,24 +651,26 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     // shared sines leave it to phase 2b, behind the barrier)
     auto gamma_sines = [&](int first, int stride, bool with_G) {
         const int nsteps = (a.debug & 1) ? 0 : N;
-        const Trig<T> trig(true);
+        const Trig<T> trig(LONGH);       // (short horizons: one evaluation per lane -- pinning the constants costs more moves than it saves)
         const T m17 = sMean[17], i17 = sInv[17];
         // item 3n + r -- r = 0 sincos(gamma_n), 1 sin(x17 at t_n+1), 2 sin(x17 at the midpoint); the last
         // item is sin(x17 at t_0).  One wave's DS operations complete in order, so the reads see the
         // chain's stores.
         // (and one more: sincos(gamma_N), which only the geometry of the last node reads -- row N, slots 2 / 3)
+        // (no branch in the item: clamped reads and selects; a sine item's unused cosine goes to a free slot of its row, [6] / [7])
         for (int i = first; i <= 3 * nsteps + (nsteps > 0 ? 1 : 0); i += stride) {
-            const bool last = i == 3 * nsteps + 1;
-            const int n = last ? nsteps : (i == 3 * nsteps ? 0 : i / 3), r = last ? 0 : (i == 3 * nsteps ? 3 : i - 3 * n);
-            const T g_n = n == 0 ? ga0 : sG[8 * (n - 1) + 5];
-            const T g_m = n == 0 ? gam0 : (n == 1 ? ga0 : sG[8 * (n - 2) + 5]);
+            const bool last = i == 3 * nsteps + 1, t0 = i == 3 * nsteps;
+            const int n = last ? nsteps : (t0 ? 0 : i / 3), r = last ? 0 : (t0 ? 3 : i - 3 * n);
+            const T r1 = sG[8 * max(n - 1, 0) + 5], r2 = sG[8 * max(n - 2, 0) + 5];
+            const T g_n = n == 0 ? ga0 : r1;
+            const T g_m = n == 0 ? gam0 : (n == 1 ? ga0 : r2);
             const T s17a = (g_m - m17) * i17, s17b = (g_n - m17) * i17;
             T sv, cv;
             trig.sincos(r == 0 ? g_n : (r == 1 ? s17b : (r == 2 ? (s17a + s17b) / T(2) : s17a)), &sv, &cv);
-            if (last) { sG[8 * n + 2] = sv; sG[8 * n + 3] = cv; }
-            else if (r == 0) { sG[8 * n] = sv; sG[8 * n + 1] = cv; }
-            else if (r == 3) sG[8 * N] = sv;
-            else sG[8 * n + 2 + r] = sv;
+            // sine: row n [0] (sincos gamma_n), [3] / [4] (x17 at the step's end / midpoint), row N [0] (x17 at t_0), row N [2] (gamma_N)
+            const int at_s = last ? 8 * n + 2 : (t0 ? 8 * N : 8 * n + (r == 0 ? 0 : 2 + r));
+            const int at_c = last ? 8 * n + 3 : (t0 ? 8 * N + 6 : 8 * n + (r == 0 ? 1 : 5 + r));
+            sG[at_s] = sv; sG[at_c] = cv;
         }
         if (with_G) gamma_G(first, stride);
     };
