@@ -477,12 +477,14 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 // LONGH: the long-horizon instance (3 N + 2 > 64, compiled-in model, plain launches): shared gamma sines, the gamma table
 // shared between workgroups, geometry waves chasing the theta wave.  A separate instantiation, so that none of that code sits
 // in the instruction stream of the C2-sized kernels (their layout is touchy: +0.15 us at C2 with the code merely present).
-template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false, bool LONGH = false>
+template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false, bool LONGH = false, int CKC = 0>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
-    const int N = a.N, CK = a.CK, K = a.K;
-    const int cks = a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
+    // CKC: the candidates per workgroup as a literal (16: the single-problem step) -- row strides become immediates of the
+    // LDS instructions, one address register per plane is bumped once per trip of the theta chain's loop
+    const int N = a.N, CK = CKC ? CKC : a.CK, K = a.K;
+    const int cks = CKC == 16 ? 4 : a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
     auto uses = [&](int plane) { return (used >> plane) & 1u; };
@@ -2076,6 +2078,18 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel_lean(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT, false, true>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_lean16(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true, false, false, 16>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_long_lean16(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true, false, true, 16>(a);
 }
 
 template <typename T, int MODEL, int VT>
