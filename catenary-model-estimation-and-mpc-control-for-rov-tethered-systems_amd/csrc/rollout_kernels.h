@@ -2082,6 +2082,18 @@ rollout_kernel_lean(const RolloutArgs<T> a) {
 
 template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
+rollout_kernel16(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, false, false, false, 16>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_long16(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, false, false, true, 16>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
 rollout_kernel_lean16(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT, false, true, false, false, 16>(a);
 }

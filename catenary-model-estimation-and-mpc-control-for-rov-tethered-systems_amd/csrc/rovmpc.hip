@@ -874,9 +874,12 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, in
                       !a.done_flag && !a.plant_next;
     auto kern = rollout_kernel<T, MODEL, VT>;
     if constexpr (MODEL == MODEL_BUILTIN) {
-        const bool ck16 = lean && a.CK == 16 && a.ck_shift == 4;               // the literal-CK instance (see rollout_body, CKC)
-        if (3 * a.N + 2 > 64) kern = ck16 ? rollout_kernel_long_lean16<T, MODEL, VT> : lean ? rollout_kernel_long_lean<T, MODEL, VT> : rollout_kernel_long<T, MODEL, VT>;      // long horizons: see rollout_body, LONGH
-        else if (lean) kern = ck16 ? rollout_kernel_lean16<T, MODEL, VT> : rollout_kernel_lean<T, MODEL, VT>;             // (no lean instance of the interpreter kernel)
+        const bool ck16 = a.CK == 16 && a.ck_shift == 4;                       // the literal-CK instances (see rollout_body, CKC)
+        if (3 * a.N + 2 > 64)                                                  // long horizons: see rollout_body, LONGH
+            kern = lean ? (ck16 ? rollout_kernel_long_lean16<T, MODEL, VT> : rollout_kernel_long_lean<T, MODEL, VT>)
+                        : (ck16 ? rollout_kernel_long16<T, MODEL, VT> : rollout_kernel_long<T, MODEL, VT>);
+        else if (lean) kern = ck16 ? rollout_kernel_lean16<T, MODEL, VT> : rollout_kernel_lean<T, MODEL, VT>;   // (no lean instance of the interpreter kernel)
+        else if (ck16) kern = rollout_kernel16<T, MODEL, VT>;
     }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
