@@ -32,6 +32,9 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 #ifndef ROVMPC_JIT_FMAP
 #define ROVMPC_JIT_FMAP 0            // feature map of a hiprtc-specialised build (a literal there)
 #endif
+#ifndef ROVMPC_JIT_CKC
+#define ROVMPC_JIT_CKC 0             // candidates per workgroup of a hiprtc-specialised build as a literal (0: run-time)
+#endif
 #ifndef ROVMPC_JIT_USED
 #define ROVMPC_JIT_USED 0xffffffffu
 #endif
@@ -2130,7 +2133,7 @@ struct HandoffArgs {
 };
 
 // a.U / a.result / a.epoch are already this step's.
-template <typename T, int MODEL, int VT>
+template <typename T, int MODEL, int VT, int CKC = 0>
 RV_DEV void closed_loop_step_body(const RolloutArgs<T> &a0, const HandoffArgs &p) {
     const long long g = p.step;
     RolloutArgs<T> a = a0;
@@ -2144,13 +2147,19 @@ RV_DEV void closed_loop_step_body(const RolloutArgs<T> &a0, const HandoffArgs &p
     a.publish = g + 1 < p.T;
     a.plant_next = g + 1 < p.T ? p.exo + (size_t)(g + 1) * ROVMPC_STATE_LEN : nullptr;
     a.plant_state = const_cast<double *>(a0.state);
-    rollout_body<T, MODEL, VT, true>(a);
+    rollout_body<T, MODEL, VT, true, false, false, false, CKC>(a);
 }
 
 template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 closed_loop_step_kernel(const RolloutArgs<T> a, const HandoffArgs p) {
     closed_loop_step_body<T, MODEL, VT>(a, p);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+closed_loop_step_kernel16(const RolloutArgs<T> a, const HandoffArgs p) {
+    closed_loop_step_body<T, MODEL, VT, 16>(a, p);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

@@ -32,6 +32,7 @@ struct rovmpc_handle {
     bool has_model = false, builtin = false;
     int model_kind = MODEL_INTERP;   // MODEL_BUILTIN | MODEL_INTERP | MODEL_JIT
     hipFunction_t jit_fn = nullptr;  // MODEL_JIT: kernel of the run-time specialised module
+    int jit_ckc = 0;                 // candidates per workgroup the module was specialised for (0: run-time)
     hipFunction_t jit_fn_step = nullptr;   //            its pipelined closed-loop step entry
     int jit_gi = 0, jit_ts = 0;            //            structure found in the rows (ROVMPC_JIT_GI / ROVMPC_JIT_TS of rollout_kernels.h)
     hipStream_t pipe_streams[2] = {nullptr, nullptr};     // pipelined closed loop: launches alternate between the two
@@ -610,7 +611,7 @@ static void jit_structure(const rovmpc_handle *h, const int32_t *code_th, int n_
 }
 
 static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, int n_th, const int32_t *code_ga, int n_ga,
-                              const double *consts, int gi, int ts) {
+                              const double *consts, int gi, int ts, int ckc) {
     const char *real = h->cfg.dtype == ROVMPC_F64 ? "double" : "float";
     // the slots a stage sets itself (everything else is a row of a node, or the midpoint of two)
     const unsigned state_mask = h->cfg.feature_map == ROVMPC_FEATURES_GEN2 ? 0xf000u        // theta, gamma, cos theta, sin gamma
@@ -623,6 +624,7 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     std::string s;
     s += "#define ROVMPC_JIT_FMAP " + std::to_string(h->cfg.feature_map) + "\n";
     s += "#define ROVMPC_JIT_NSUB " + std::to_string(subs.size()) + "\n";
+    s += "#define ROVMPC_JIT_CKC " + std::to_string(ckc) + "\n";      // candidates per workgroup as a literal (rollout_body, CKC)
     s += "#define ROVMPC_JIT_GI " + std::to_string(gi) + "\n#define ROVMPC_JIT_TS " + std::to_string(ts) + "\n";
     s += "#define ROVMPC_JIT_NGSUB " + std::to_string(gsubs.size()) + "\n";
     {
@@ -646,9 +648,9 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e, const Trig<" + real + "> &tg) { typedef " + real +
          " T; (void)e; (void)tg; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a);\n}\n";
+         "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", false, false, false, false, ROVMPC_JIT_CKC>(a);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a, const rovmpc::HandoffArgs p) {\n    rovmpc::closed_loop_step_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ">(a, p);\n}\n";
+         "> a, const rovmpc::HandoffArgs p) {\n    rovmpc::closed_loop_step_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", ROVMPC_JIT_CKC>(a, p);\n}\n";
     if (getenv("ROVMPC_JIT_DUMP")) fprintf(stderr, "[rovmpc] hiprtc translation unit:\n%s\n", s.c_str());
     return s;
 }
@@ -794,18 +796,25 @@ extern "C" int rovmpc_set_model(rovmpc_handle *h, int32_t n_features, const doub
     }
     h->builtin = same;
     h->model_kind = same ? MODEL_BUILTIN : MODEL_INTERP;
-    h->jit_fn = nullptr; h->jit_fn_step = nullptr; h->jit_gi = 0; h->jit_ts = 0;
+    h->jit_fn = nullptr; h->jit_fn_step = nullptr; h->jit_gi = 0; h->jit_ts = 0; h->jit_ckc = 0;
     h->err.clear();
     if (!same && !h->cfg.force_interpreter && !h->cfg.jit_off && n_features <= 18) {
         std::string why;
         int gi = 0, ts = 0;
         jit_structure(h, code_theta, n_code_theta, code_gamma, n_code_gamma, &gi, &ts);
-        const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts, gi, ts);
+        // the geometry this model will run with (configure_geometry below decides the same): 16 candidates per workgroup
+        // become a literal of the module
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+        const int ck_jit = pick_ck(&h->cfg, MODEL_JIT, jit_lds_planes(h->used_planes, h->cfg.vt_mode, h->cfg.feature_map), h->n_cu, gi);
+        const int ckc = (ck_jit == 16 && !getenv("ROVMPC_JIT_NO_CKC")) ? 16 : 0;
+        const std::string src = jit_source(h, code_theta, n_code_theta, code_gamma, n_code_gamma, consts, gi, ts, ckc);
         hipFunction_t fn = jit_build(h->cfg.device, src, why, &h->jit_fn_step);
-        if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; h->jit_gi = gi; h->jit_ts = ts; }
+        if (fn) { h->jit_fn = fn; h->model_kind = MODEL_JIT; h->jit_gi = gi; h->jit_ts = ts; h->jit_ckc = ckc; }
         else h->err = "hiprtc specialisation unavailable, using the bytecode interpreter: " + why;
     }
     if (const char *why = configure_geometry(h, h->model_kind)) FAIL(h, ROVMPC_ERR_INVALID, "%s", why);
+    if (h->model_kind == MODEL_JIT && h->jit_ckc && h->CK != h->jit_ckc) FAIL(h, ROVMPC_ERR_INVALID, "internal: the specialised module was built for %d candidates per workgroup, the geometry has %d", h->jit_ckc, h->CK);
     h->has_model = true;
     return ROVMPC_OK;
 }
@@ -2125,7 +2134,7 @@ static int closed_loop_workspace(rovmpc_handle *h, HandoffArgs &p, hipStream_t s
 template <typename T, int VT>
 static hipError_t launch_step(const rovmpc_handle *h, const RolloutArgs<T> &a, const HandoffArgs &p, hipStream_t s, bool probe, int *capacity) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
-    auto kern = closed_loop_step_kernel<T, MODEL_BUILTIN, VT>;
+    auto kern = (a.CK == 16 && a.ck_shift == 4) ? closed_loop_step_kernel16<T, MODEL_BUILTIN, VT> : closed_loop_step_kernel<T, MODEL_BUILTIN, VT>;   // (literal-CK instance: rollout_body, CKC)
     if (probe) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
