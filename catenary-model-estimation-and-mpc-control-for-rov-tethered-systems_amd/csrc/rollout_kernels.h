@@ -32,6 +32,9 @@ constexpr int MODEL_JIT     = 2;   // any bytecode, translated to C++ and compil
 #ifndef ROVMPC_JIT_FMAP
 #define ROVMPC_JIT_FMAP 0            // feature map of a hiprtc-specialised build (a literal there)
 #endif
+#ifndef ROVMPC_JIT_N
+#define ROVMPC_JIT_N 0               // horizon of a hiprtc-specialised build as a literal (0: run-time)
+#endif
 #ifndef ROVMPC_JIT_CKC
 #define ROVMPC_JIT_CKC 0             // candidates per workgroup of a hiprtc-specialised build as a literal (0: run-time)
 #endif
@@ -480,13 +483,14 @@ template <typename T> __host__ __device__ inline size_t rollout_lds_elems(int N,
 // LONGH: the long-horizon instance (3 N + 2 > 64, compiled-in model, plain launches): shared gamma sines, the gamma table
 // shared between workgroups, geometry waves chasing the theta wave.  A separate instantiation, so that none of that code sits
 // in the instruction stream of the C2-sized kernels (their layout is touchy: +0.15 us at C2 with the code merely present).
-template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false, bool LONGH = false, int CKC = 0>
+template <typename T, int MODEL, int VT, bool HANDOFF = false, bool LEAN = false, bool SAMPLE = false, bool LONGH = false, int CKC = 0, int NC = 0>
 RV_DEV void rollout_body(const RolloutArgs<T> &a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *smem = reinterpret_cast<T *>(smem_raw);
     // CKC: the candidates per workgroup as a literal (16: the single-problem step) -- row strides become immediates of the
     // LDS instructions, one address register per plane is bumped once per trip of the theta chain's loop
-    const int N = a.N, CK = CKC ? CKC : a.CK, K = a.K;
+    // NC: the horizon as a literal too -- then every plane of the LDS layout sits at an immediate offset of one address
+    const int N = NC ? NC : a.N, CK = CKC ? CKC : a.CK, K = a.K;
     const int cks = CKC == 16 ? 4 : a.ck_shift, ckm = CK - 1;        // i / CK == i >> cks, i % CK == i & ckm
     const unsigned used = MODEL == MODEL_JIT ? (unsigned)ROVMPC_JIT_USED : a.used_planes;
     const int fmap = MODEL == MODEL_JIT ? (int)ROVMPC_JIT_FMAP : a.fmap;
@@ -2133,7 +2137,7 @@ struct HandoffArgs {
 };
 
 // a.U / a.result / a.epoch are already this step's.
-template <typename T, int MODEL, int VT, int CKC = 0>
+template <typename T, int MODEL, int VT, int CKC = 0, int NC = 0>
 RV_DEV void closed_loop_step_body(const RolloutArgs<T> &a0, const HandoffArgs &p) {
     const long long g = p.step;
     RolloutArgs<T> a = a0;
@@ -2147,7 +2151,7 @@ RV_DEV void closed_loop_step_body(const RolloutArgs<T> &a0, const HandoffArgs &p
     a.publish = g + 1 < p.T;
     a.plant_next = g + 1 < p.T ? p.exo + (size_t)(g + 1) * ROVMPC_STATE_LEN : nullptr;
     a.plant_state = const_cast<double *>(a0.state);
-    rollout_body<T, MODEL, VT, true, false, false, false, CKC>(a);
+    rollout_body<T, MODEL, VT, true, false, false, false, CKC, NC>(a);
 }
 
 template <typename T, int MODEL, int VT>

@@ -624,7 +624,7 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     std::string s;
     s += "#define ROVMPC_JIT_FMAP " + std::to_string(h->cfg.feature_map) + "\n";
     s += "#define ROVMPC_JIT_NSUB " + std::to_string(subs.size()) + "\n";
-    s += "#define ROVMPC_JIT_CKC " + std::to_string(ckc) + "\n";      // candidates per workgroup as a literal (rollout_body, CKC)
+    s += "#define ROVMPC_JIT_CKC " + std::to_string(ckc) + "\n#define ROVMPC_JIT_N " + std::to_string((ckc && !getenv("ROVMPC_JIT_NO_NC")) ? h->cfg.N : 0) + "\n";      // candidates per workgroup as a literal (rollout_body, CKC)
     s += "#define ROVMPC_JIT_GI " + std::to_string(gi) + "\n#define ROVMPC_JIT_TS " + std::to_string(ts) + "\n";
     s += "#define ROVMPC_JIT_NGSUB " + std::to_string(gsubs.size()) + "\n";
     {
@@ -648,9 +648,9 @@ static std::string jit_source(const rovmpc_handle *h, const int32_t *code_th, in
     s += std::string("template <> __device__ ") + real + " jit_f_gamma<" + real + ">(const " + real + " *x, const " + real + " *e, const Trig<" + real + "> &tg) { typedef " + real +
          " T; (void)e; (void)tg; return " + f_ga + "; }\n";
     s += "}\nextern \"C\" __global__ void __launch_bounds__(512) rovmpc_rollout_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", false, false, false, false, ROVMPC_JIT_CKC>(a);\n}\n";
+         "> a) {\n    rovmpc::rollout_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", false, false, false, false, ROVMPC_JIT_CKC, ROVMPC_JIT_N>(a);\n}\n";
     s += "extern \"C\" __global__ void __launch_bounds__(512) rovmpc_closed_loop_step_jit(const rovmpc::RolloutArgs<" + std::string(real) +
-         "> a, const rovmpc::HandoffArgs p) {\n    rovmpc::closed_loop_step_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", ROVMPC_JIT_CKC>(a, p);\n}\n";
+         "> a, const rovmpc::HandoffArgs p) {\n    rovmpc::closed_loop_step_body<" + real + ", rovmpc::MODEL_JIT, " + std::to_string(h->cfg.vt_mode) + ", ROVMPC_JIT_CKC, ROVMPC_JIT_N>(a, p);\n}\n";
     if (getenv("ROVMPC_JIT_DUMP")) fprintf(stderr, "[rovmpc] hiprtc translation unit:\n%s\n", s.c_str());
     return s;
 }
