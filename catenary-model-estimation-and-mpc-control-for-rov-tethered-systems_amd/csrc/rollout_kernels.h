@@ -2105,6 +2105,26 @@ rollout_kernel_lean16(const RolloutArgs<T> a) {
     rollout_body<T, MODEL, VT, false, true, false, false, 16>(a);
 }
 
+// (and the horizon of the headline configuration, N = 20, as a literal as well: double precision only)
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_lean16_n20(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true, false, false, 16, 20>(a);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel16_n20(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, false, false, false, 16, 20>(a);
+}
+
+// (BASELINE configuration 3: N = 50, single precision)
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+rollout_kernel_long_lean16_n50(const RolloutArgs<T> a) {
+    rollout_body<T, MODEL, VT, false, true, false, true, 16, 50>(a);
+}
+
 template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 rollout_kernel_long_lean16(const RolloutArgs<T> a) {
@@ -2164,6 +2184,12 @@ template <typename T, int MODEL, int VT>
 __global__ void __launch_bounds__(512)
 closed_loop_step_kernel16(const RolloutArgs<T> a, const HandoffArgs p) {
     closed_loop_step_body<T, MODEL, VT, 16>(a, p);
+}
+
+template <typename T, int MODEL, int VT>
+__global__ void __launch_bounds__(512)
+closed_loop_step_kernel16_n20(const RolloutArgs<T> a, const HandoffArgs p) {
+    closed_loop_step_body<T, MODEL, VT, 16, 20>(a, p);
 }
 
 // After the all-reduce(min): every rank holds every rank's record; pick the lexicographic

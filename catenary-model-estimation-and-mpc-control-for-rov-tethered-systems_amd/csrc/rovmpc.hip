@@ -883,12 +883,21 @@ static hipError_t launch_one(const rovmpc_handle *h, const RolloutArgs<T> &a, in
                       !a.done_flag && !a.plant_next;
     auto kern = rollout_kernel<T, MODEL, VT>;
     if constexpr (MODEL == MODEL_BUILTIN) {
-        const bool ck16 = a.CK == 16 && a.ck_shift == 4;                       // the literal-CK instances (see rollout_body, CKC)
-        if (3 * a.N + 2 > 64)                                                  // long horizons: see rollout_body, LONGH
+        // the literal-CK instances (see rollout_body, CKC), and with them the literal horizons of the BASELINE configurations
+        // (NC: N = 20 in double precision, N = 50 in single); ROVMPC_NO_LITERAL_N=1 keeps the horizon a run-time value
+        const bool ck16 = a.CK == 16 && a.ck_shift == 4;
+        const bool literal_n = !getenv("ROVMPC_NO_LITERAL_N");           // (read per launch: the parity tests switch it inside one process)
+        if (3 * a.N + 2 > 64) {                                                // long horizons: see rollout_body, LONGH
             kern = lean ? (ck16 ? rollout_kernel_long_lean16<T, MODEL, VT> : rollout_kernel_long_lean<T, MODEL, VT>)
                         : (ck16 ? rollout_kernel_long16<T, MODEL, VT> : rollout_kernel_long<T, MODEL, VT>);
-        else if (lean) kern = ck16 ? rollout_kernel_lean16<T, MODEL, VT> : rollout_kernel_lean<T, MODEL, VT>;   // (no lean instance of the interpreter kernel)
-        else if (ck16) kern = rollout_kernel16<T, MODEL, VT>;
+            if constexpr (sizeof(T) == 4) { if (lean && ck16 && a.N == 50 && literal_n) kern = rollout_kernel_long_lean16_n50<T, MODEL, VT>; }
+        } else if (lean) {
+            kern = ck16 ? rollout_kernel_lean16<T, MODEL, VT> : rollout_kernel_lean<T, MODEL, VT>;   // (no lean instance of the interpreter kernel)
+            if constexpr (sizeof(T) == 8) { if (ck16 && a.N == 20 && literal_n) kern = rollout_kernel_lean16_n20<T, MODEL, VT>; }
+        } else if (ck16) {
+            kern = rollout_kernel16<T, MODEL, VT>;
+            if constexpr (sizeof(T) == 8) { if (a.N == 20 && literal_n) kern = rollout_kernel16_n20<T, MODEL, VT>; }
+        }
     }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2135,6 +2144,7 @@ template <typename T, int VT>
 static hipError_t launch_step(const rovmpc_handle *h, const RolloutArgs<T> &a, const HandoffArgs &p, hipStream_t s, bool probe, int *capacity) {
     const size_t lds = rollout_lds_elems<T>(a.N, a.CK, MODEL_BUILTIN, VT) * sizeof(T);
     auto kern = (a.CK == 16 && a.ck_shift == 4) ? closed_loop_step_kernel16<T, MODEL_BUILTIN, VT> : closed_loop_step_kernel<T, MODEL_BUILTIN, VT>;   // (literal-CK instance: rollout_body, CKC)
+    if constexpr (sizeof(T) == 8) { if (a.CK == 16 && a.ck_shift == 4 && a.N == 20 && !getenv("ROVMPC_NO_LITERAL_N")) kern = closed_loop_step_kernel16_n20<T, MODEL_BUILTIN, VT>; }
     if (probe) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -690,6 +690,40 @@ def test_a_candidate_does_not_depend_on_its_neighbours(rv):
         assert np.array_equal(traj[5], traj[k]) and np.array_equal(traj2[5], traj2[k]) and np.array_equal(traj[5], traj2[k])
 
 
+@pytest.mark.parametrize("N,K,dtype,B", [(20, 4096, "f64", 1), (20, 512, "f64", 8), (50, 16384, "f32", 1)])
+def test_literal_horizon_instances_equal_the_run_time_ones(rv, N, K, dtype, B, monkeypatch):
+    """The BASELINE horizons (N = 20 in double, N = 50 in single precision, 16 candidates per workgroup) run on kernel
+    instances with N and CK as literals; ROVMPC_NO_LITERAL_N=1 keeps the horizon a run-time value.  Same arithmetic, other
+    addressing: every record bit for bit, single launches and batched ones."""
+    import torch
+    cfg = rv.MPCConfig(N=N, K=K, dtype=dtype)
+    dev = torch.device("cuda", 0)
+    states = np.empty((B, 16)); U = np.empty((B, K, N, 3), dtype=cfg.np_dtype)
+    for b in range(B):
+        states[b], U[b] = rv.synthetic_problem(K, N, seed=91 + b, dtype=cfg.np_dtype)
+    d_s, d_U = torch.tensor(states, device=dev), torch.tensor(U, device=dev)
+    out = []
+    with rv.Engine(cfg) as e:
+        for literal in (True, False):
+            if literal:
+                monkeypatch.delenv("ROVMPC_NO_LITERAL_N", raising=False)
+            else:
+                monkeypatch.setenv("ROVMPC_NO_LITERAL_N", "1")
+            d_r = torch.zeros((B, e.result_len), dtype=torch.float64, device=dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            if B == 1:
+                e.step_device(d_s.data_ptr(), d_U.data_ptr(), d_r.data_ptr(), stream)
+                J = e.rollout_costs(states[0], U[0])
+            else:
+                e.step_batch_device(B, d_s.data_ptr(), d_U.data_ptr(), d_r.data_ptr(), stream)
+                J = None
+            torch.cuda.synchronize()
+            out.append((d_r.cpu().numpy().copy(), J))
+    assert np.array_equal(out[0][0], out[1][0])
+    if out[0][1] is not None:
+        assert np.array_equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("scale,K", [(20.0, 64), (40.0, 40), (20.0, 4096)])
 def test_theta_steps_beyond_the_angle_addition_bound(rv, orc, scale, K):
     """Steps with |theta_{n+1} - theta_n| beyond the bound of the angle addition (fast vehicles): the chain notes them and, one
