@@ -598,11 +598,31 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
         // Horizons of up to 64 steps can keep the path in registers -- lane n holds gamma_{n+1} -- and store it once behind
         // the loop: a masked store and its two jumps in every step of the chain cost more than three selects; with two steps
         // per trip, the second on the first one's names, there is no copy of gamma_n on the chain either (C2: -0.4 us).  As
-        // a literal of the loop only: the plain short-horizon instance always (N <= 20 there), the hand-off and sampling
-        // instances through a second copy of the loop.  (Long-horizon instance: measured, +0.2 us at C3 -- as it was.)
+        // a literal of the loop only: the plain short-horizon instances always (N <= 20 there), every other one through a
+        // second copy of the loop (C3, literal N = 50: -0.9 us).
         T kept = T(0);
         auto run = [&](auto HOLD, auto EULER, auto KEEP) {
             auto one = [&](int n, const T gam, const T ga) -> T {
+                if (!JGI) {
+                    // The compiled-in row dgamma/dt = s15 - p17 with every fused multiply-add spelt out (the recurrence amplifies
+                    // rounding: left to the compiler's contraction, two instances of this loop need not round alike)
+                    const T s17a = (gam - m17) * i17, d17 = ga - m17, s17b = d17 * i17;   // np.roll delay slot, simply.py:35-38
+                    const T p17m = HOLD.value ? s17a : m_fma(i17, d17, s17a) * T(0.5);
+                    const T p17e = HOLD.value ? s17a : s17b;
+                    const T k1g = m_fma(i15, ga - m15, -s17a);
+                    T gan;
+                    if (EULER.value) {
+                        gan = m_fma(k1g, hstep, ga);                                // main_fun.py:762
+                    } else {
+                        const T k2g = m_fma(i15, m_fma(hh, k1g, ga) - m15, -p17m);
+                        const T k3g = m_fma(i15, m_fma(hh, k2g, ga) - m15, -p17m);
+                        const T k4g = m_fma(i15, m_fma(hstep, k3g, ga) - m15, -p17e);
+                        gan = m_fma(h6, m_fma(T(2), k3g, m_fma(T(2), k2g, k1g)) + k4g, ga);   // :66
+                    }
+                    if (KEEP.value) { if (lane == n) kept = gan; }
+                    else if (lane == 0) sG[GROW * n + 5] = gan;
+                    return gan;
+                }
                 const T s17a = (gam - m17) * i17, s17b = (ga - m17) * i17;      // np.roll delay slot, simply.py:35-38
                 const T p17m = HOLD.value ? s17a : (s17a + s17b) / T(2);
                 const T p17e = HOLD.value ? s17a : s17b;
@@ -640,8 +660,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             else if (hold) run(BoolC<true>{}, BoolC<false>{}, KEEP);
             else run(BoolC<false>{}, BoolC<false>{}, KEEP);
         };
-        constexpr bool CAN_KEEP = !JGI && MODEL == MODEL_BUILTIN && !LONGH;
-        if (CAN_KEEP && !HANDOFF && !SAMPLE) run_mode(BoolC<true>{});
+        constexpr bool CAN_KEEP = !JGI && MODEL == MODEL_BUILTIN;
+        if (CAN_KEEP && !HANDOFF && !SAMPLE && (!LONGH || (NC > 0 && NC <= 64))) run_mode(BoolC<true>{});
         else if (CAN_KEEP && N <= 64) run_mode(BoolC<true>{});
         else run_mode(BoolC<false>{});
     };
