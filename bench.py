@@ -479,6 +479,13 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     for i in range(presteps + args.warmup):
         one_step(i)
+    if smpc is None:
+        # drain the untimed steps SPINNING: a host thread that blocks for the milliseconds they take comes back from a deep
+        # sleep state and feeds the first timed launches late (measured: +2 us per step over a 20-step region)
+        ev_w = torch.cuda.Event()
+        ev_w.record(streams[-1])
+        while not ev_w.query():
+            pass
     if dist is not None:
         fence(); fence()                      # (the collective library's barrier is slow the first times it runs: 139 us, then 35)
     fence()                                   # barrier + synchronise: the GPU idles only for this one round trip

@@ -2,7 +2,7 @@
 // hipcc -O3 --offload-arch=gfx950 -o fma_latency fma_latency.hip && ./fma_latency
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <typename T, int CHAINS>
+template <typename T, int CHAINS, bool SHORT = false>
 __global__ void chain_kernel(T *out, unsigned long long *ticks, int iters, T a, T b) {
     T x[CHAINS];
 #pragma unroll
@@ -14,8 +14,13 @@ __global__ void chain_kernel(T *out, unsigned long long *ticks, int iters, T a, 
         for (int k = 0; k < 16; ++k) {
 #pragma unroll
             for (int c = 0; c < CHAINS; ++c) {
-                if constexpr (sizeof(T) == 8) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
-                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+                if constexpr (SHORT) {          // VOP2 encodings (4 bytes): x += a * b
+                    if constexpr (sizeof(T) == 8) asm volatile("v_fmac_f64_e32 %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+                    else asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+                } else {                        // VOP3 encodings (8 bytes)
+                    if constexpr (sizeof(T) == 8) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+                    else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+                }
             }
         }
     }
@@ -27,11 +32,11 @@ __global__ void chain_kernel(T *out, unsigned long long *ticks, int iters, T a, 
     out[threadIdx.x] = s;
     if (threadIdx.x == 0) { ticks[0] = t1 - t0; ticks[1] = w1 - w0; }
 }
-template <typename T, int CHAINS> void run(const char *name, int threads) {
+template <typename T, int CHAINS, bool SHORT = false> void run(const char *name, int threads) {
     T *out; unsigned long long *ticks, h[2];
     hipMalloc(&out, 64 * sizeof(T) * 8); hipMalloc(&ticks, 16);
     const int iters = 4096;
-    for (int r = 0; r < 2; ++r) chain_kernel<T, CHAINS><<<1, threads>>>(out, ticks, iters, T(0.999), T(1e-3));
+    for (int r = 0; r < 2; ++r) chain_kernel<T, CHAINS, SHORT><<<1, threads>>>(out, ticks, iters, T(0.999), T(1e-3));
     hipDeviceSynchronize();
     hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
     const double n = (double)iters * 16 * CHAINS;
@@ -43,5 +48,9 @@ int main() {
     run<double, 1>("fma_f64", 64); run<double, 2>("fma_f64", 64); run<double, 4>("fma_f64", 64);
     run<double, 1>("fma_f64", 16); run<double, 2>("fma_f64", 16);
     run<float, 1>("fma_f32", 64); run<float, 2>("fma_f32", 64); run<float, 4>("fma_f32", 64);
+    // 4-byte encodings: is a lone wave's issue rate an instruction-fetch rate?
+    run<double, 1, true>("fmac_f64", 64); run<double, 4, true>("fmac_f64", 64); run<double, 8, true>("fmac_f64", 64);
+    run<float, 1, true>("fmac_f32", 64); run<float, 4, true>("fmac_f32", 64); run<float, 8, true>("fmac_f32", 64);
+    run<double, 8>("fma_f64", 64);
     return 0;
 }
