@@ -1245,7 +1245,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     ct = ct * cd - st * sd;
                     st = sn;
                     const bool anchor = PAR.value && ((n + 1) & 15) == 0;        // (anchors fall on odd steps)
-                    if (anchor || __any(big)) {                                   // rare
+                    if (__builtin_expect(anchor || __any(big), 0)) {              // rare (the hint moves the block out of the loop's instruction stream)
                         T fs, fc;
                         trig.sincos(thn, &fs, &fc);
                         if (anchor || big) { st = fs; ct = fc; }
