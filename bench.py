@@ -492,17 +492,24 @@ def main():
     t0 = time.perf_counter()
     for e, st in zip(ev0, streams):
         e.record(st)
+    _ta = time.perf_counter()
     for i in range(args.steps):
         rec = one_step(i)
+    _tb = time.perf_counter()
     for e, st in zip(ev1, streams):
         e.record(st)
+    _tc = time.perf_counter()
     if smpc is None:
         # spin on the end events before the blocking synchronise below: a blocked host thread is woken tens of
         # microseconds after the GPU finishes, which is 5 % of a 20-step timed region (the synchronise still brackets it)
         while not all(e.query() for e in ev1):
             pass
+    _td = time.perf_counter()
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    if os.environ.get("ROVMPC_BENCH_TRACE_BRACKET"):
+        print("[bracket] record0 %.1f us, launches %.1f, record1 %.1f, spin %.1f, fence %.1f, total %.1f" % tuple(
+            1e6 * x for x in (_ta - t0, _tb - _ta, _tc - _tb, _td - _tc, time.perf_counter() - _td, time.perf_counter() - t0)), file=sys.stderr)
     # per stream: event span / launches on that stream = launch-to-launch period of the kernel
     launches = [len(range(j, args.steps, S)) for j in range(S)]
     region_ms = sum(a_.elapsed_time(b_) / max(n_, 1) for a_, b_, n_ in zip(ev0, ev1, launches)) / S * args.steps
