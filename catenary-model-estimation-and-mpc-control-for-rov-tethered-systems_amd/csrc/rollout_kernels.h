@@ -635,7 +635,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     const T k3g = fgam(((ga + hh * k2g) - m15) * i15, p17m);
                     const T k4g = fgam(((ga + hstep * k3g) - m15) * i15, p17e);
                     gan = ga + h6 * (k1g + T(2) * k2g + T(2) * k3g + k4g);      // :66
-                    if (JGI && lane == 0) {      // gamma's stage states, for a dtheta/dt that reads them (slots 2..4 of the row)
+                    if (JGI && !ROVMPC_JIT_TS && lane == 0) {      // gamma's stage states, for a dtheta/dt that reads them (slots 2..4 of the row)
                         sG[GROW * n + 2] = ga + hh * k1g; sG[GROW * n + 3] = ga + hh * k2g; sG[GROW * n + 4] = ga + hstep * k3g;
                     }
                 }
@@ -660,8 +660,8 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             else if (hold) run(BoolC<true>{}, BoolC<false>{}, KEEP);
             else run(BoolC<false>{}, BoolC<false>{}, KEEP);
         };
-        constexpr bool CAN_KEEP = !JGI && MODEL == MODEL_BUILTIN;
-        if (CAN_KEEP && !HANDOFF && !SAMPLE && (!LONGH || (NC > 0 && NC <= 64))) run_mode(BoolC<true>{});
+        constexpr bool CAN_KEEP = MODEL == MODEL_BUILTIN || (JGI && ROVMPC_JIT_TS != 0);   // (loaded rows whose dtheta/dt reads gamma's stage states store those per step anyway: measured, no gain)
+        if (CAN_KEEP && MODEL == MODEL_BUILTIN && !HANDOFF && !SAMPLE && (!LONGH || (NC > 0 && NC <= 64))) run_mode(BoolC<true>{});
         else if (CAN_KEEP && N <= 64) run_mode(BoolC<true>{});
         else run_mode(BoolC<false>{});
     };
