@@ -1546,7 +1546,7 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
             T rs, rc, qs, qc;
             add_angle(sa, ca, d, rs, rc);
             add_angle(sb, cb, e, qs, qc);
-            if (__any(bigx | bigy)) {
+            if (__builtin_expect(__any(bigx | bigy), 0)) {
                 T fs, fc;
                 m_sincos(x, &fs, &fc);
                 if (bigx) { rs = fs; rc = fc; }
@@ -1778,14 +1778,14 @@ RV_DEV void rollout_body(const RolloutArgs<T> &a) {
                     // sincos(gamma_{n+1}) is in the table; theta alone advances by angle addition
                     if (need_trig && n + 1 < nsteps) {
                         sg = o.sgn; cg = o.cgn;
-                        if (((n + 1) & 15) == 0) m_sincos(thn, &st, &ct);
-                        else {
-                            const T d = thn - th;
-                            T rs, rc;
-                            add_angle(st, ct, d, rs, rc);
-                            if (__any(!(m_abs(d) < T(0.0078125)))) { T fs, fc; m_sincos(thn, &fs, &fc); if (!(m_abs(d) < T(0.0078125))) { rs = fs; rc = fc; } }
-                            st = rs; ct = rc;
-                        }
+                        // (as in the compiled-in chain: the addition always, anchors and large steps as ONE rare block that the
+                        // hint moves out of the loop's instruction stream)
+                        const T d = thn - th;
+                        const bool big = !(m_abs(d) < T(0.0078125)), anchor = ((n + 1) & 15) == 0;
+                        T rs, rc;
+                        add_angle(st, ct, d, rs, rc);
+                        if (__builtin_expect(anchor || __any(big), 0)) { T fs, fc; m_sincos(thn, &fs, &fc); if (anchor || big) { rs = fs; rc = fc; } }
+                        st = rs; ct = rc;
                     }
                 } else
                 if (need_trig && n + 1 < nsteps) {
